@@ -1,0 +1,153 @@
+/*
+ * yfs.h — C ABI of libyfs.so, the MI355X (gfx950) hot path of yolo-from-scratch.
+ *
+ * The reference (3141592/yolo-from-scratch) is pure Python on torch.nn and has no FFI of its
+ * own; every entry point below names the reference call site (file:line in the upstream repo)
+ * whose work it takes over.  Entry points marked "no reference code" implement behaviour the
+ * reference only specifies in README.md / assets/yolo_loss_function.png; SPEC.md freezes their
+ * conventions.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch's caching allocator in the
+ *     Python host); the library never allocates, frees or retains memory.  Scratch is passed in;
+ *     its size comes from the matching yfs_*_workspace_bytes().
+ *   - tensors are dense in the documented layout.  Activations are NHWC ("channels last").
+ *   - `stream` is a hipStream_t passed as void*.  Kernels are enqueued on it; nothing synchronises.
+ *   - return value: 0 = success, negative = yfs_status.  yfs_last_error() gives the thread-local
+ *     message of the last failure on the calling thread.
+ *   - no global mutable state: calls from several host threads on distinct streams are safe.
+ */
+#ifndef YFS_H
+#define YFS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    YFS_OK = 0,
+    YFS_ERR_INVALID_ARG = -1,   /* null pointer, non-positive size, unsupported shape */
+    YFS_ERR_UNSUPPORTED = -2,   /* shape outside what the gfx950 kernels were built for */
+    YFS_ERR_WORKSPACE = -3,     /* workspace too small / misaligned */
+    YFS_ERR_LAUNCH = -4         /* hipGetLastError() after a launch was not hipSuccess */
+} yfs_status;
+
+int yfs_version(void);
+/* copies the calling thread's last error message (NUL-terminated, truncated to n); returns its length */
+int yfs_last_error(char *buf, size_t n);
+
+/* ---- kernel set 3: box math, decode, NMS ---------------------------------------------------- */
+
+/* iou_xywh_torch(pred, gt)  yolo_toy_regressor_torch.py:159-182 (numpy twin :121-138).
+ * pred, gt [n,4] xywh; iou_out [n] per-pair IoU (may be NULL); mean_out [1] batch mean (may be NULL).
+ * workspace: yfs_iou_xywh_workspace_bytes(n) bytes when mean_out != NULL. */
+size_t yfs_iou_xywh_workspace_bytes(int64_t n);
+int yfs_iou_xywh_f32(const float *pred, const float *gt, int64_t n, float *iou_out, float *mean_out,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* box_iou_xyxy(xywh_to_xyxy(a), xywh_to_xyxy(b))  practice/yolo_toy_regressor_3_torch.py:106-119
+ * variant: 0 = A4 op order (above), 1 = A4b (side clamps, union+1e-9), 2 = A4c
+ * (practice/yolo_toy_regressor_torch_20251015.py:226-278). */
+int yfs_iou_variant_f32(const float *pred, const float *gt, int64_t n, int variant, float *iou_out, void *stream);
+
+/* N x M IoU in the op order of iou_xywh_torch (:159-182).  a [na,4], b [nb,4] xywh -> out [na,nb]. */
+int yfs_pairwise_iou_f32(const float *a, int64_t na, const float *b, int64_t nb, float *out, void *stream);
+
+/* decode_head(t)  practice/yolo_toy_regressor_3_torch.py:290-295; t,out [n,4]. */
+int yfs_decode_head_f32(const float *t, int64_t n, float prior_w, float prior_h, float *out, void *stream);
+/* decode_xywh(raw)  practice/yolo_toy_regressor_torch_20251015.py:411-421; t,out [n,4]. */
+int yfs_decode_xywh_f32(const float *t, int64_t n, float *out, void *stream);
+
+/* Grid/anchor decode + confidence = objectness x class probability.  No reference code
+ * (README.md:44-46); decode_head is its S=1, A=1 case.
+ * raw [N,S,S,A,5+C]; anchors [A,2] grid units; boxes [N,S*S*A,4] xywh; score [N,S*S*A] best-class
+ * score; cls [N,S*S*A] int32 best class; all_scores [N,S*S*A,C] or NULL. */
+int yfs_decode_grid_f32(const float *raw, int64_t N, int S, int A, int C, const float *anchors, float *boxes,
+                        float *score, int32_t *cls, float *all_scores, void *stream);
+/* YOLOv1 head decode (README.md:91-93, :44-46).  pred [N,S,S,5B+C] -> boxes [N,S*S*B,4], score, cls. */
+int yfs_decode_v1_f32(const float *pred, int64_t N, int S, int B, int C, float *boxes, float *score,
+                      int32_t *cls, void *stream);
+
+/* Per-image class-wise greedy NMS.  No reference code (README.md:47, :68).
+ * boxes [N,A,4] xywh; score [N,A]; cls [N,A] int32; keep [N,A] int32 kept indices in descending
+ * score order, -1 padded; count [N] int32.  A <= YFS_NMS_MAX_BOXES. */
+#define YFS_NMS_MAX_BOXES 2048
+int yfs_nms_classwise_f32(const float *boxes, const float *score, const int32_t *cls, int64_t N, int A,
+                          float score_thr, float iou_thr, int32_t *keep, int32_t *count, void *stream);
+/* decode_grid + NMS in one launch with the image's boxes resident in LDS (BASELINE config 4). */
+int yfs_decode_nms_f32(const float *raw, int64_t N, int S, int A, int C, const float *anchors, float score_thr,
+                       float iou_thr, float *boxes, float *score, int32_t *cls, int32_t *keep, int32_t *count,
+                       void *stream);
+
+/* ---- kernel set 4: YOLOv2 target assignment -------------------------------------------------- */
+/* No reference code (README.md:55-59; nearest: estimate_size_priors practice/yolo_toy_regressor_3_torch.py:278-286).
+ * gt [N,G,5] (cx,cy,w,h,class), rows with w<=0 or h<=0 are padding; anchors [A,2] grid units;
+ * pred_boxes [N,S,S,A,4] xywh or NULL; obj_mask, ignore_mask uint8 [N,S,S,A]; targets [N,S,S,A,5]. */
+int yfs_assign_targets_v2_f32(const float *gt, int64_t N, int G, int S, int A, const float *anchors,
+                              const float *pred_boxes, float ignore_thr, uint8_t *obj_mask,
+                              uint8_t *ignore_mask, float *targets, void *stream);
+
+/* ---- kernel set 2: composite YOLOv1 loss ------------------------------------------------------ */
+/* Slots in at loss_fn(preds, yb)  yolo_toy_regressor_torch.py:329 (nn.MSELoss() at :377); the
+ * composite form is specified by assets/yolo_loss_function.png and README.md:97-115 only.
+ * pred, target, grad [N,S,S,5B+C] fp32; loss_out [5] = total, coord, obj, noobj, cls (each / N);
+ * grad = d total / d pred (written in the same launch; may be NULL). */
+size_t yfs_yolov1_loss_workspace_bytes(int64_t N, int S);
+int yfs_yolov1_loss_fwd_bwd_f32(const float *pred, const float *target, int64_t N, int S, int B, int C,
+                                float l_coord, float l_noobj, float *loss_out, float *grad, void *workspace,
+                                size_t workspace_bytes, void *stream);
+/* nn.MSELoss()  yolo_toy_regressor_torch.py:377 (mean over all n elements) + gradient. */
+size_t yfs_mse_workspace_bytes(int64_t n);
+int yfs_mse_fwd_bwd_f32(const float *pred, const float *target, int64_t n, float *loss_out, float *grad,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- kernel set 1: Conv2D block = Conv2d(k, stride, pad k/2, bias) + LeakyReLU ------------------
+ * Conv2D(in_ch, out_ch, k, s)  yolo_toy_regressor_torch.py:206-211, called 24x from :218-254.
+ * bf16 NHWC activations, bf16 weights [Cout,K,K,Cin], fp32 accumulate on MFMA. */
+
+/* y = leaky(conv(x, w) + bias).  x [N,H,W,Cin] bf16, w [Cout,K,K,Cin] bf16, bias [Cout] fp32,
+ * y [N,Ho,Wo,Cout] bf16.  Cin % 8 == 0 (conv1's Cin=3 goes through yfs_im2col_bf16 first). */
+int yfs_conv2d_fwd_bf16(const void *x, const void *w, const float *bias, void *y, int64_t N, int H, int W,
+                        int Cin, int Cout, int K, int stride, float slope, void *stream);
+/* dx = conv_transpose(dz, w) [* leaky'(x_act) when x_act != NULL].  dz [N,Ho,Wo,Cout] bf16,
+ * wt [Cin,K,K,Cout] bf16 = w transposed and spatially flipped (yfs_weight_prep), dx [N,H,W,Cin] bf16.
+ * x_act: this layer's input when it is itself a LeakyReLU output, so the previous block's
+ * activation derivative is applied in the epilogue. */
+int yfs_conv2d_dgrad_bf16(const void *dz, const void *wt, const void *x_act, void *dx, int64_t N, int H, int W,
+                          int Cin, int Cout, int K, int stride, float slope, void *stream);
+/* dw [Cout,K,K,Cin] fp32 (+)= sum_pixels dz (x) x ; db [Cout] fp32 (+)= sum_pixels dz.
+ * accumulate != 0 adds into dw/db (gradient accumulation), else overwrites. */
+size_t yfs_conv2d_wgrad_workspace_bytes(int64_t N, int H, int W, int Cin, int Cout, int K, int stride);
+int yfs_conv2d_wgrad_bf16(const void *x, const void *dz, float *dw, float *db, int64_t N, int H, int W, int Cin,
+                          int Cout, int K, int stride, int accumulate, void *workspace, size_t workspace_bytes,
+                          void *stream);
+/* dz = dy * (y > 0 ? 1 : slope): LeakyReLU backward on the saved block output (:210). n elements bf16. */
+int yfs_leaky_bwd_bf16(const void *dy, const void *y, void *dz, int64_t n, float slope, void *stream);
+/* fp32 master weight [Cout,K,K,Cin] -> bf16 copy w_bf16 (same layout) and wt_bf16 [Cin,K,K,Cout]
+ * flipped (for dgrad); either output may be NULL. */
+int yfs_weight_prep_bf16(const float *w, void *w_bf16, void *wt_bf16, int Cout, int K, int Cin, void *stream);
+/* im2col for the Cin=3 stem (feat.0, :220): x [N,H,W,Cin] (fp32 if x_is_f32 else bf16) ->
+ * cols [N*Ho*Wo, Kpad] bf16 with (kh,kw,ci) order, zero padded to Kpad. */
+int yfs_im2col_bf16(const void *x, int x_is_f32, void *cols, int64_t N, int H, int W, int Cin, int K, int stride,
+                    int Kpad, void *stream);
+
+/* MaxPool2d(2, 2)  yolo_toy_regressor_torch.py:216 on NHWC bf16.  H, W even. */
+int yfs_maxpool2_fwd_bf16(const void *x, void *y, int64_t N, int H, int W, int C, void *stream);
+/* dx = route(dy) to the first max of each window [* leaky'(x) when fuse_leaky: x is a LeakyReLU output]. */
+int yfs_maxpool2_bwd_bf16(const void *x, const void *dy, void *dx, int64_t N, int H, int W, int C,
+                          int fuse_leaky, float slope, void *stream);
+
+/* clip_grad_norm_ + SGD(momentum, weight_decay)  yolo_toy_regressor_torch.py:333, :378-381, one pass.
+ * sumsq: device scalar with the squared global grad norm (yfs_sumsq_f32 accumulates it);
+ * p -= lr * (buf = momentum*buf + clip*g + wd*p). first_step != 0 initialises buf = g'. */
+int yfs_sumsq_f32(const float *g, int64_t n, float *sumsq_accum, void *stream);
+int yfs_sgd_step_f32(float *p, const float *g, float *buf, int64_t n, const float *sumsq, float max_norm,
+                     float lr, float momentum, float weight_decay, int first_step, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YFS_H */

@@ -1,0 +1,164 @@
+"""Kernel set 3 on the MI355X vs the CPU oracle, through the C ABI (ctypes -> libyfs.so)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import yolo_from_scratch_amd as y
+from yolo_from_scratch_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def test_iou_golden_bit_exact(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g4_iou.npz"))
+    pred, gt = g["pred"], g["gt"]
+    rows = y.iou_xywh_rows(_t(pred), _t(gt)).cpu().numpy()
+    np.testing.assert_array_equal(rows.astype(np.float64), g["a4_np_rows"])      # reference's own values
+    np.testing.assert_array_equal(rows, oracle.iou_xywh(pred, gt))
+    assert abs(y.iou_xywh_torch(_t(pred), _t(gt)) - float(g["a4_mean"])) < 1e-6
+    assert abs(y.iou_xywh_torch(_t(g["ka_pred"]), _t(g["ka_gt"])) - 0.1250000298) < 1e-7
+    np.testing.assert_array_equal(y.iou_variant(_t(pred), _t(gt), 1).cpu().numpy(), g["a4b"])
+    np.testing.assert_array_equal(y.iou_variant(_t(pred), _t(gt), 2).cpu().numpy(), g["a4c"])
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 257, 100000])
+def test_iou_rows_sizes(n):
+    rng = np.random.default_rng(n)
+    p = rng.uniform(0, 1, (n, 4)).astype(np.float32)
+    q = rng.uniform(0, 1, (n, 4)).astype(np.float32)
+    np.testing.assert_array_equal(y.iou_xywh_rows(_t(p), _t(q)).cpu().numpy(), oracle.iou_xywh(p, q))
+    assert abs(y.iou_xywh_torch(_t(p), _t(q)) - oracle.iou_xywh_mean(p, q)) < 1e-6
+
+
+@pytest.mark.parametrize("na,nb", [(1, 1), (5, 3), (64, 256), (100, 845), (845, 845), (130, 1031)])
+def test_pairwise_iou_bit_exact(na, nb):
+    rng = np.random.default_rng(na * 1000 + nb)
+    a = rng.uniform(0, 1, (na, 4)).astype(np.float32)
+    b = rng.uniform(0, 1, (nb, 4)).astype(np.float32)
+    a[:, 2:] *= 0.5
+    b[:, 2:] *= 0.5
+    np.testing.assert_array_equal(y.pairwise_iou(_t(a), _t(b)).cpu().numpy(), oracle.pairwise_iou(a, b))
+
+
+def test_single_box_decoders(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g5_decode.npz"))
+    t = g["t"]
+    # fp32 tolerance from north_star: 1e-5 relative (exp/sigmoid differ by ulps between libm and the GPU)
+    np.testing.assert_allclose(y.decode_head(_t(t)).cpu().numpy(), g["decode_head"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(y.decode_xywh(_t(t)).cpu().numpy(), g["decode_xywh"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(y.decode_head(_t(t)).cpu().numpy(), oracle.decode_head(t), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("N,S,A,C", [(1, 1, 1, 3), (3, 7, 2, 20), (5, 13, 5, 20), (2, 19, 5, 20), (2, 13, 3, 80)])
+def test_decode_grid(N, S, A, C):
+    raw = synth.raw_head_v2(N, S, A, C, seed=N * 100 + S)
+    anchors = np.abs(np.random.default_rng(5).standard_normal((A, 2))).astype(np.float32) * 3 + 0.5
+    ob, os_, oc, oa = oracle.decode_grid(raw, anchors, all_scores=True)
+    b, s, c, a = y.decode_grid(_t(raw), _t(anchors), all_scores=True)
+    np.testing.assert_allclose(b.cpu().numpy(), ob, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(s.cpu().numpy(), os_, rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(a.cpu().numpy(), oa, rtol=1e-5, atol=1e-9)
+    np.testing.assert_array_equal(c.cpu().numpy(), oc)       # argmax over raw logits: exact
+    np.testing.assert_allclose(y.class_scores(_t(raw), _t(anchors)).cpu().numpy(), oa, rtol=1e-5, atol=1e-9)
+
+
+def test_decode_v1():
+    rng = np.random.default_rng(3)
+    pred = rng.uniform(0, 1, (9, 7, 7, 30)).astype(np.float32)
+    ob, os_, oc = oracle.decode_v1(pred, 2, 20)
+    b, s, c = y.decode_v1(_t(pred), 2, 20)
+    np.testing.assert_array_equal(b.cpu().numpy(), ob)
+    np.testing.assert_array_equal(s.cpu().numpy(), os_)
+    np.testing.assert_array_equal(c.cpu().numpy(), oc)
+
+
+def _nms_case(N, A, seed, ncls=20, pass_frac=0.15, tie=False, clustered=False):
+    rng = np.random.default_rng(seed)
+    boxes = rng.uniform(0, 1, (N, A, 4)).astype(np.float32)
+    boxes[..., 2:] = boxes[..., 2:] * 0.4 + 0.05
+    if clustered:   # many heavy overlaps
+        centers = rng.uniform(0.2, 0.8, (N, 6, 2)).astype(np.float32)
+        pick = rng.integers(0, 6, (N, A))
+        boxes[..., :2] = np.take_along_axis(centers, pick[..., None].repeat(2, -1), 1) + \
+            rng.normal(0, 0.02, (N, A, 2)).astype(np.float32)
+    score = rng.uniform(0, 1, (N, A)).astype(np.float32)
+    score = np.where(rng.uniform(0, 1, (N, A)) < pass_frac, score * 0.95 + 0.05, score * 0.049).astype(np.float32)
+    if tie:
+        score = (np.round(score * 8) / 8).astype(np.float32)     # many exact ties -> index order must decide
+        boxes[:, 1::2] = boxes[:, 0::2][:, :boxes[:, 1::2].shape[1]]  # duplicate boxes
+    cls = rng.integers(0, ncls, (N, A)).astype(np.int32)
+    return boxes, score, cls
+
+
+@pytest.mark.parametrize("N,A,kw", [
+    (4, 98, {}), (3, 845, {}), (2, 845, {"pass_frac": 1.0}), (2, 845, {"pass_frac": 0.0}),
+    (3, 845, {"tie": True, "ncls": 2}), (3, 845, {"clustered": True, "ncls": 1, "pass_frac": 0.6}),
+    (2, 1, {}), (2, 63, {"pass_frac": 1.0}), (2, 64, {"pass_frac": 1.0}), (2, 65, {"pass_frac": 1.0, "clustered": True}),
+    (1, 2048, {"pass_frac": 0.9, "clustered": True, "ncls": 3}), (64, 845, {"clustered": True}),
+])
+def test_nms_kept_indices_bit_exact(N, A, kw):
+    boxes, score, cls = _nms_case(N, A, seed=N * 7 + A, **kw)
+    keep_o, cnt_o = oracle.nms(boxes, score, cls, 0.05, 0.5)
+    keep, cnt = y.nms(_t(boxes), _t(score), _t(cls), 0.05, 0.5)
+    np.testing.assert_array_equal(cnt.cpu().numpy(), cnt_o)
+    np.testing.assert_array_equal(keep.cpu().numpy(), keep_o)
+
+
+def test_nms_idempotent_and_sorted():
+    """Size-independent properties: kept scores are non-increasing; NMS of the kept set keeps everything."""
+    boxes, score, cls = _nms_case(16, 845, seed=99, clustered=True)
+    keep, cnt = y.nms(_t(boxes), _t(score), _t(cls))
+    keep, cnt = keep.cpu().numpy(), cnt.cpu().numpy()
+    for n in range(16):
+        k = keep[n, :cnt[n]]
+        assert (keep[n, cnt[n]:] == -1).all()
+        assert (np.diff(score[n, k]) <= 0).all()
+        kb, ks, kc = boxes[n, k][None], score[n, k][None], cls[n, k][None]
+        keep2, cnt2 = y.nms(_t(kb), _t(ks), _t(kc))
+        assert int(cnt2[0]) == cnt[n]
+        np.testing.assert_array_equal(keep2.cpu().numpy()[0, :cnt[n]], np.arange(cnt[n]))
+
+
+@pytest.mark.parametrize("N,S,A,C", [(8, 13, 5, 20), (3, 7, 2, 20), (2, 19, 5, 20)])
+def test_fused_decode_nms(N, S, A, C):
+    """Fused launch == separate decode + NMS on the GPU, and == the CPU NMS fed the GPU's decoded boxes
+    (decode differs from libm by ulps, so NMS is compared on identical boxes: SURVEY.md §7 'hard parts')."""
+    raw = synth.raw_head_v2(N, S, A, C, seed=1234)
+    anchors = synth.VOC_ANCHORS[:A]
+    b, s, c, keep, cnt = [t.cpu().numpy() for t in y.decode_nms(_t(raw), _t(anchors), 0.05, 0.5)]
+    b2, s2, c2 = y.decode_grid(_t(raw), _t(anchors))
+    np.testing.assert_array_equal(b, b2.cpu().numpy())
+    np.testing.assert_array_equal(s, s2.cpu().numpy())
+    np.testing.assert_array_equal(c, c2.cpu().numpy())
+    keep_o, cnt_o = oracle.nms(b, s, c, 0.05, 0.5)
+    np.testing.assert_array_equal(cnt, cnt_o)
+    np.testing.assert_array_equal(keep, keep_o)
+    frac = (s >= 0.05).mean()
+    assert 0.02 < frac < 0.5
+
+
+def test_config4_full_size_properties():
+    """BASELINE config 4 at full size (N=1024, 845 boxes, C=20): CPU NMS on a 64-image slice is bit-equal;
+    whole batch satisfies the structural properties."""
+    N = 1024
+    raw = synth.raw_head_v2(N, 13, 5, 20, seed=1234)
+    op = y.DecodeNms(N, 13, 5, 20, DEV)
+    b, s, c, keep, cnt = [t.cpu().numpy() for t in op(_t(raw), _t(synth.VOC_ANCHORS))]
+    sl = slice(480, 544)
+    keep_o, cnt_o = oracle.nms(b[sl], s[sl], c[sl], 0.05, 0.5)
+    np.testing.assert_array_equal(keep[sl], keep_o)
+    np.testing.assert_array_equal(cnt[sl], cnt_o)
+    valid = keep >= 0
+    assert (valid.sum(1) == cnt).all()
+    ks = np.take_along_axis(s, np.where(valid, keep, 0), 1)
+    assert (ks[valid] >= 0.05).all()
+    d = np.diff(np.where(valid, ks, -np.inf), axis=1)
+    assert (d[valid[:, 1:]] <= 0).all()

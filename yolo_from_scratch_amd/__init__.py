@@ -1,0 +1,8 @@
+"""yolo_from_scratch_amd — the MI355X-native hot path of yolo-from-scratch behind the reference's
+own Python call surface.  Everything here runs hand-written gfx950 HIP kernels from libyfs.so
+(C ABI in include/yfs.h); there is no CPU fallback (the CPU oracle in oracle/ is test-only)."""
+from ._lib import YfsError, lib, LIB_PATH  # noqa: F401
+from .boxes import (iou_xywh_torch, iou_xywh_rows, iou_variant, pairwise_iou, decode_head, decode_xywh,  # noqa: F401
+                    decode_grid, class_scores, decode_v1, nms, decode_nms, DecodeNms)
+from .loss import YoloV1Loss, MSELoss  # noqa: F401
+from .assign import assign_targets_v2, VOC_ANCHORS  # noqa: F401

@@ -1,0 +1,126 @@
+// Kernel set 4: YOLOv2 anchor target assignment + ignore-IoU mask.
+// No reference code (README.md:55-59 of the reference names the feature); conventions in SPEC.md §4.
+// Built with -ffp-contract=off: the masks must equal the CPU oracle's bit for bit.
+#include "yfs_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ void unstage_floats(float* __restrict__ dst, int len, const float* lds, int tid) {
+    // lds[i] -> dst[i]; dst is only 4-byte aligned in general (per-image offset), so align the body.
+    const int dskew = (int)((reinterpret_cast<uintptr_t>(dst) >> 2) & 3);
+    const int head = (4 - dskew) & 3;
+    const int h = head < len ? head : len;
+    if (tid < h) dst[tid] = lds[tid];
+    const int nq = (len - h) >> 2;
+    float4* d4 = reinterpret_cast<float4*>(dst + h);
+    for (int q = tid; q < nq; q += kThreads) {
+        const float* s = lds + h + 4 * q;     // LDS side is unaligned when h != 0: scalar reads
+        d4[q] = make_float4(s[0], s[1], s[2], s[3]);
+    }
+    const int done = h + nq * 4;
+    if (tid < len - done) dst[done + tid] = lds[done + tid];
+}
+
+// One workgroup per image.  Phase 1: one thread per gt resolves (cell, anchor) and the regression
+// targets into LDS.  Phase 2: one thread per (cell, anchor) scans the image's gts in index order —
+// the first gt that maps to it wins (deterministic, no atomics) — and takes the max IoU of its
+// predicted box over all valid gts for the ignore mask.  Targets leave through LDS with 16-byte stores.
+__global__ void __launch_bounds__(kThreads) assign_v2_kernel(const float* __restrict__ gt, int G, int S, int A,
+                                                             const float* __restrict__ anchors,
+                                                             const float4* __restrict__ pred_boxes, float ignore_thr,
+                                                             uint8_t* __restrict__ obj_mask,
+                                                             uint8_t* __restrict__ ignore_mask,
+                                                             float* __restrict__ targets) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int64_t n = blockIdx.x;
+    const int per = S * S * A;
+    // carve: per gt 10 floats: slot(int), tx, ty, tw, th, cls, cx, cy, w, h
+    float* ginfo = lds;
+    float* tstage = lds + ((10 * G + 3) & ~3);
+    const float* g = gt + n * (int64_t)G * 5;
+    const float fS = (float)S;
+    for (int k = tid; k < G; k += kThreads) {
+        const float cx = g[5 * k], cy = g[5 * k + 1], w = g[5 * k + 2], h = g[5 * k + 3];
+        float* o = ginfo + 10 * k;
+        int slot = -1;
+        if (w > 0.0f && h > 0.0f) {
+            const float fx = cx * fS, fy = cy * fS;
+            int col = (int)floorf(fx), row = (int)floorf(fy);
+            col = col < 0 ? 0 : (col > S - 1 ? S - 1 : col);
+            row = row < 0 ? 0 : (row > S - 1 ? S - 1 : row);
+            const float gw = w * fS, gh = h * fS;
+            int best = 0;
+            float bi = -1.0f;
+            for (int a = 0; a < A; ++a) {
+                const float aw = anchors[2 * a], ah = anchors[2 * a + 1];
+                const float inter = fminf(gw, aw) * fminf(gh, ah);
+                const float uni = gw * gh + aw * ah - inter;
+                const float iou = uni > 0.0f ? inter / uni : 0.0f;
+                if (iou > bi) { bi = iou; best = a; }
+            }
+            slot = (row * S + col) * A + best;
+            o[1] = fx - (float)col;
+            o[2] = fy - (float)row;
+            o[3] = logf(gw / anchors[2 * best]);
+            o[4] = logf(gh / anchors[2 * best + 1]);
+            o[5] = g[5 * k + 4];
+        }
+        o[0] = __int_as_float(slot);
+        o[6] = cx; o[7] = cy; o[8] = w; o[9] = h;
+    }
+    __syncthreads();
+    for (int c = tid; c < per; c += kThreads) {
+        int owner = -1;
+        for (int k = 0; k < G; ++k) {
+            if (__float_as_int(ginfo[10 * k]) == c) { owner = k; break; }
+        }
+        float* t = tstage + 5 * c;
+        if (owner >= 0) {
+            const float* o = ginfo + 10 * owner;
+            t[0] = o[1]; t[1] = o[2]; t[2] = o[3]; t[3] = o[4]; t[4] = o[5];
+        } else {
+            t[0] = 0.0f; t[1] = 0.0f; t[2] = 0.0f; t[3] = 0.0f; t[4] = 0.0f;
+        }
+        uint8_t ign = 0;
+        if (pred_boxes) {
+            const float4 p = pred_boxes[n * per + c];
+            float best = 0.0f;
+            for (int k = 0; k < G; ++k) {
+                const float* o = ginfo + 10 * k;
+                if (__float_as_int(o[0]) < 0) continue;
+                const float v = yfs_iou_xywh(p.x, p.y, p.z, p.w, o[6], o[7], o[8], o[9]);
+                if (v > best) best = v;
+            }
+            ign = (uint8_t)((best > ignore_thr) && owner < 0);
+        }
+        obj_mask[n * per + c] = (uint8_t)(owner >= 0);
+        ignore_mask[n * per + c] = ign;
+    }
+    __syncthreads();
+    unstage_floats(targets + n * (int64_t)per * 5, per * 5, tstage, tid);
+}
+
+}  // namespace
+
+YFS_API int yfs_assign_targets_v2_f32(const float* gt, int64_t N, int G, int S, int A, const float* anchors,
+                                      const float* pred_boxes, float ignore_thr, uint8_t* obj_mask,
+                                      uint8_t* ignore_mask, float* targets, void* stream) {
+    YFS_REQUIRE(gt && anchors && obj_mask && ignore_mask && targets, YFS_ERR_INVALID_ARG,
+                "yfs_assign_targets_v2_f32: null pointer");
+    YFS_REQUIRE(N > 0 && G > 0 && S > 0 && A > 0, YFS_ERR_INVALID_ARG,
+                "yfs_assign_targets_v2_f32: bad shape N=%lld G=%d S=%d A=%d", (long long)N, G, S, A);
+    const size_t lds = ((size_t)((10 * G + 3) & ~3) + (size_t)S * S * A * 5 + 8) * sizeof(float);
+    YFS_REQUIRE(lds <= 150 * 1024, YFS_ERR_UNSUPPORTED,
+                "yfs_assign_targets_v2_f32: S=%d A=%d G=%d needs %zu bytes of LDS (max 153600)", S, A, G, lds);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)assign_v2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        YFS_REQUIRE(e == hipSuccess, YFS_ERR_LAUNCH, "yfs_assign_targets_v2_f32: cannot reserve %zu bytes of LDS", lds);
+    }
+    assign_v2_kernel<<<dim3((unsigned)N), dim3(kThreads), lds, (hipStream_t)stream>>>(
+        gt, G, S, A, anchors, (const float4*)pred_boxes, ignore_thr, obj_mask, ignore_mask, targets);
+    YFS_CHECK_LAUNCH("assign_v2_kernel");
+    return YFS_OK;
+}

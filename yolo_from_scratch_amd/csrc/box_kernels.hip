@@ -1,0 +1,586 @@
+// Kernel set 3: box math, grid/anchor decode, class-wise NMS (gfx950).
+// Built with -ffp-contract=off: IoU-vs-threshold decisions must match the CPU oracle bit for bit,
+// so every multiply and add rounds separately, in the op order of the reference's iou_xywh_torch
+// (yolo_toy_regressor_torch.py:159-182).
+#include "yfs_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// ------------------------------------------------------------------------------------------
+// Stage the global floats [src, src+len) into LDS with 16-byte loads.  `src` is only 4-byte
+// aligned in general (per-image offsets such as n*21125 floats), so the copy starts at the
+// enclosing 16-byte boundary; the element src[i] lands at lds[skew + i].  The extra <=12 bytes
+// on either side lie in the same 16-byte granule as a valid element, hence inside the allocation.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int stage_floats(const float* __restrict__ src, int len, float* lds, int tid) {
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(src);
+    const int skew = (int)((addr >> 2) & 3);
+    const float4* base = reinterpret_cast<const float4*>(addr - (uintptr_t)skew * 4);
+    const int nq = (skew + len + 3) >> 2;
+    float4* l4 = reinterpret_cast<float4*>(lds);
+    for (int q = tid; q < nq; q += kThreads) l4[q] = base[q];
+    return skew;
+}
+
+struct Decoded {
+    float x, y, w, h, score;
+    int cls;
+};
+
+// raw (tx,ty,tw,th,to, C logits) at r[0..5+C), read with stride 1 from LDS.
+__device__ __forceinline__ Decoded decode_one(const float* r, int C, int row, int col, int S, float aw, float ah) {
+    Decoded d;
+    const float fS = (float)S;
+    d.x = (yfs_sigmoid(r[0]) + (float)col) / fS;
+    d.y = (yfs_sigmoid(r[1]) + (float)row) / fS;
+    d.w = aw * expf(r[2]) / fS;
+    d.h = ah * expf(r[3]) / fS;
+    const float conf = yfs_sigmoid(r[4]);
+    float m = r[5];
+    int best = 0;
+    for (int c = 1; c < C; ++c) {
+        float v = r[5 + c];
+        if (v > m) { m = v; best = c; }
+    }
+    float sum = 0.0f;
+    for (int c = 0; c < C; ++c) sum += expf(r[5 + c] - m);
+    d.score = conf * (1.0f / sum);
+    d.cls = best;
+    return d;
+}
+
+// ---------------- paired IoU + deterministic mean -----------------------------------------
+__global__ void __launch_bounds__(kThreads) iou_rows_kernel(const float4* __restrict__ pred,
+                                                            const float4* __restrict__ gt, int64_t n,
+                                                            float* __restrict__ iou_out, float* __restrict__ partial) {
+    __shared__ float wsum[kThreads / 64];
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    float v = 0.0f;
+    if (i < n) {
+        float4 p = pred[i], g = gt[i];
+        v = yfs_iou_xywh(p.x, p.y, p.z, p.w, g.x, g.y, g.z, g.w);
+        if (iou_out) iou_out[i] = v;
+    }
+    if (partial) {
+        float s = yfs_wave_sum(v);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    }
+}
+
+// one block: sums `count` partials in a fixed order, writes out[0] = sum * scale
+__global__ void __launch_bounds__(kThreads) finalize_sum_kernel(const float* __restrict__ partial, int64_t count,
+                                                                float scale, float* __restrict__ out) {
+    __shared__ float wsum[kThreads / 64];
+    float acc = 0.0f;
+    for (int64_t i = threadIdx.x; i < count; i += kThreads) acc += partial[i];
+    float s = yfs_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) * scale;
+}
+
+__device__ __forceinline__ float clamp01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
+
+__global__ void __launch_bounds__(kThreads) iou_variant_kernel(const float4* __restrict__ pred,
+                                                               const float4* __restrict__ gt, int64_t n, int variant,
+                                                               float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    float4 p = pred[i], g = gt[i];
+    float r;
+    if (variant == 0) {
+        r = yfs_iou_xywh(p.x, p.y, p.z, p.w, g.x, g.y, g.z, g.w);
+    } else if (variant == 1) {   // box_iou_xyxy, practice/yolo_toy_regressor_3_torch.py:112-119
+        float px1 = p.x - p.z / 2, py1 = p.y - p.w / 2, px2 = p.x + p.z / 2, py2 = p.y + p.w / 2;
+        float gx1 = g.x - g.z / 2, gy1 = g.y - g.w / 2, gx2 = g.x + g.z / 2, gy2 = g.y + g.w / 2;
+        float iw = fminf(px2, gx2) - fmaxf(px1, gx1), ih = fminf(py2, gy2) - fmaxf(py1, gy1);
+        iw = iw > 0 ? iw : 0; ih = ih > 0 ? ih : 0;
+        float inter = iw * ih;
+        float aw = px2 - px1, ah = py2 - py1, bw = gx2 - gx1, bh = gy2 - gy1;
+        aw = aw > 0 ? aw : 0; ah = ah > 0 ? ah : 0; bw = bw > 0 ? bw : 0; bh = bh > 0 ? bh : 0;
+        float uni = aw * ah + bw * bh - inter + 1e-9f;
+        r = inter / uni;
+    } else {                     // older iou_xywh_torch, practice/yolo_toy_regressor_torch_20251015.py:226-278
+        const float eps = 1e-7f;
+        float pw = p.z > eps ? p.z : eps, ph = p.w > eps ? p.w : eps;
+        float gw = g.z > eps ? g.z : eps, gh = g.w > eps ? g.w : eps;
+        float px1 = clamp01(p.x - 0.5f * pw), py1 = clamp01(p.y - 0.5f * ph);
+        float px2 = clamp01(p.x + 0.5f * pw), py2 = clamp01(p.y + 0.5f * ph);
+        float gx1 = clamp01(g.x - 0.5f * gw), gy1 = clamp01(g.y - 0.5f * gh);
+        float gx2 = clamp01(g.x + 0.5f * gw), gy2 = clamp01(g.y + 0.5f * gh);
+        float iw = fminf(px2, gx2) - fmaxf(px1, gx1), ih = fminf(py2, gy2) - fmaxf(py1, gy1);
+        iw = iw > 0 ? iw : 0; ih = ih > 0 ? ih : 0;
+        float inter = iw * ih;
+        float aw = px2 - px1, ah = py2 - py1, bw = gx2 - gx1, bh = gy2 - gy1;
+        aw = aw > 0 ? aw : 0; ah = ah > 0 ? ah : 0; bw = bw > 0 ? bw : 0; bh = bh > 0 ? bh : 0;
+        float uni = aw * ah + bw * bh - inter;
+        r = clamp01(inter / (uni + eps));
+    }
+    out[i] = r;
+}
+
+// ---------------- N x M pairwise IoU ------------------------------------------------------
+// Each block: 64 rows of `a` (one per lane of a wave, kept in registers as corners) x a strip
+// of columns; `b` corners are staged in LDS and read as wave-wide broadcasts.
+constexpr int kPairCols = 256;
+__global__ void __launch_bounds__(kThreads) pairwise_iou_kernel(const float4* __restrict__ a, int64_t na,
+                                                                const float4* __restrict__ b, int64_t nb,
+                                                                float* __restrict__ out) {
+    __shared__ float4 bc[kPairCols];
+    const int64_t j0 = (int64_t)blockIdx.x * kPairCols;
+    const int64_t i0 = (int64_t)blockIdx.y * 64;
+    {
+        int64_t j = j0 + threadIdx.x;
+        float4 v = j < nb ? b[j] : make_float4(0, 0, 0, 0);
+        bc[threadIdx.x] = make_float4(v.x - 0.5f * v.z, v.y - 0.5f * v.w, v.x + 0.5f * v.z, v.y + 0.5f * v.w);
+    }
+    __syncthreads();
+    // thread t: column group (t & 63) * 4 .. +3, rows (t >> 6) * 16 .. +15
+    const int cg = (threadIdx.x & 63) * 4;
+    const int rbase = (threadIdx.x >> 6) * 16;
+    float4 c0 = bc[cg], c1 = bc[cg + 1], c2 = bc[cg + 2], c3 = bc[cg + 3];
+    for (int r = 0; r < 16; ++r) {
+        int64_t i = i0 + rbase + r;
+        if (i >= na) break;
+        float4 p = a[i];
+        float px1 = p.x - 0.5f * p.z, py1 = p.y - 0.5f * p.w, px2 = p.x + 0.5f * p.z, py2 = p.y + 0.5f * p.w;
+        float4 o;
+        o.x = yfs_iou_corners(px1, py1, px2, py2, c0.x, c0.y, c0.z, c0.w);
+        o.y = yfs_iou_corners(px1, py1, px2, py2, c1.x, c1.y, c1.z, c1.w);
+        o.z = yfs_iou_corners(px1, py1, px2, py2, c2.x, c2.y, c2.z, c2.w);
+        o.w = yfs_iou_corners(px1, py1, px2, py2, c3.x, c3.y, c3.z, c3.w);
+        int64_t j = j0 + cg;
+        float* dst = out + i * nb + j;
+        if (j + 3 < nb && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+            *reinterpret_cast<float4*>(dst) = o;
+        } else {
+            if (j < nb) dst[0] = o.x;
+            if (j + 1 < nb) dst[1] = o.y;
+            if (j + 2 < nb) dst[2] = o.z;
+            if (j + 3 < nb) dst[3] = o.w;
+        }
+    }
+}
+
+// ---------------- single-box decoders ------------------------------------------------------
+__global__ void __launch_bounds__(kThreads) decode_head_kernel(const float4* __restrict__ t, int64_t n, float pw,
+                                                               float ph, float4* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    float4 v = t[i];
+    float w = expf(v.z) * pw, h = expf(v.w) * ph;
+    w = w < 1e-4f ? 1e-4f : (w > 1.0f ? 1.0f : w);
+    h = h < 1e-4f ? 1e-4f : (h > 1.0f ? 1.0f : h);
+    out[i] = make_float4(yfs_sigmoid(v.x), yfs_sigmoid(v.y), w, h);
+}
+
+__global__ void __launch_bounds__(kThreads) decode_xywh_kernel(const float4* __restrict__ t, int64_t n,
+                                                               float4* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const float eps = 1e-7f, hi = 1.0f - 1e-7f;
+    float4 v = t[i];
+    float w = yfs_sigmoid(v.z), h = yfs_sigmoid(v.w);
+    w = w < eps ? eps : (w > hi ? hi : w);
+    h = h < eps ? eps : (h > hi ? hi : h);
+    out[i] = make_float4(yfs_sigmoid(v.x), yfs_sigmoid(v.y), w, h);
+}
+
+// ---------------- grid decode (stand-alone) -------------------------------------------------
+// One block decodes `bpb` consecutive boxes of the flattened [N*S*S*A] box list: the raw floats
+// are pulled into LDS with coalesced 16-byte loads (each HBM byte read exactly once), every
+// thread then owns one box and reads its 5+C floats at LDS stride D (odd D => conflict free).
+__global__ void __launch_bounds__(kThreads) decode_grid_kernel(const float* __restrict__ raw, int64_t nboxes, int S,
+                                                               int A, int C, const float* __restrict__ anchors,
+                                                               int bpb, float4* __restrict__ boxes,
+                                                               float* __restrict__ score, int32_t* __restrict__ cls,
+                                                               float* __restrict__ all_scores) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int D = 5 + C;
+    const int64_t b0 = (int64_t)blockIdx.x * bpb;
+    const int nb = (int)((nboxes - b0) < bpb ? (nboxes - b0) : bpb);
+    const int skew = stage_floats(raw + b0 * D, nb * D, lds, threadIdx.x);
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < nb) {
+        const int64_t b = b0 + t;
+        const int per = S * S * A;
+        const int bi = (int)(b % per);
+        const int a = bi % A, cell = bi / A;
+        const float* r = lds + skew + t * D;
+        Decoded d = decode_one(r, C, cell / S, cell % S, S, anchors[2 * a], anchors[2 * a + 1]);
+        boxes[b] = make_float4(d.x, d.y, d.w, d.h);
+        score[b] = d.score;
+        cls[b] = d.cls;
+        if (all_scores) {
+            const float conf = yfs_sigmoid(r[4]);
+            float m = r[5 + d.cls];
+            float sum = 0.0f;
+            for (int c = 0; c < C; ++c) sum += expf(r[5 + c] - m);
+            for (int c = 0; c < C; ++c) all_scores[b * C + c] = conf * (expf(r[5 + c] - m) / sum);
+        }
+    }
+}
+
+// YOLOv1 head decode: one thread per cell, pred staged through LDS the same way.
+__global__ void __launch_bounds__(kThreads) decode_v1_kernel(const float* __restrict__ pred, int64_t ncells, int S,
+                                                             int B, int C, float4* __restrict__ boxes,
+                                                             float* __restrict__ score, int32_t* __restrict__ cls) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int D = 5 * B + C;
+    const int64_t c0 = (int64_t)blockIdx.x * kThreads;
+    const int nc = (int)((ncells - c0) < kThreads ? (ncells - c0) : kThreads);
+    const int skew = stage_floats(pred + c0 * D, nc * D, lds, threadIdx.x);
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t >= nc) return;
+    const int64_t cell = c0 + t;
+    const int ci = (int)(cell % (S * S));
+    const int row = ci / S, col = ci % S;
+    const float* r = lds + skew + t * D;
+    int best = 0;
+    float m = r[5 * B];
+    for (int c = 1; c < C; ++c) {
+        float v = r[5 * B + c];
+        if (v > m) { m = v; best = c; }
+    }
+    const float fS = (float)S;
+    for (int j = 0; j < B; ++j) {
+        const int64_t b = cell * B + j;
+        boxes[b] = make_float4((r[5 * j] + (float)col) / fS, (r[5 * j + 1] + (float)row) / fS, r[5 * j + 2],
+                               r[5 * j + 3]);
+        score[b] = r[5 * j + 4] * m;
+        cls[b] = best;
+    }
+}
+
+// ---------------- class-wise NMS (optionally fused with the grid decode) -----------------------
+// One workgroup per image; the image's candidate boxes never leave LDS.
+//   A  filter: score >= thr -> append (key, corners, class) to LDS candidate arrays
+//      (fused: decode 256-box chunks staged through LDS first, and write boxes/score/cls out)
+//   B  rank sort by 64-bit key = (descending score, ascending index): K^2/256 compares per thread,
+//      all LDS broadcasts, two barriers
+//   C  greedy suppression in 64-row tiles: all threads build the tile's 64 x (W-b) suppression
+//      bitmask (row = lane, so the column box is a wave-wide LDS broadcast); wave 0 resolves the
+//      tile's diagonal word with register-only readlane steps, then ORs the kept rows' masks into
+//      the per-lane `removed` words
+//   D  kept indices (score order) written coalesced, -1 padded
+struct NmsArgs {
+    const float* raw;        // fused: [N, S*S*A, 5+C]
+    const float* anchors;    // fused
+    int S, A_anch, C;        // fused
+    const float4* boxes_in;  // non-fused
+    const float* score_in;
+    const int32_t* cls_in;
+    float4* boxes_out;       // fused outputs
+    float* score_out;
+    int32_t* cls_out;
+    int32_t* keep;
+    int32_t* count;
+    int A;                   // boxes per image
+    int cap;                 // A rounded up to 64
+    int bpc;                 // fused: boxes per staged chunk
+    float score_thr, iou_thr;
+};
+
+__device__ __forceinline__ unsigned long long make_key(float s, int idx) {
+    unsigned u = __float_as_uint(s);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // monotone float -> uint
+    return ((unsigned long long)(~u) << 32) | (unsigned)idx;   // ascending key = descending score, ascending idx
+}
+
+template <bool FUSED>
+__global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t n = blockIdx.x;
+    const int A = g.A, cap = g.cap;
+    // carve (all offsets multiples of 16)
+    unsigned long long* key = reinterpret_cast<unsigned long long*>(smem);          // 8*cap   (kept list aliases)
+    float4* cbox = reinterpret_cast<float4*>(smem + 8 * (size_t)cap);                // 16*cap  (mask aliases)
+    int* ccls = reinterpret_cast<int*>(smem + 24 * (size_t)cap);                     // 4*cap
+    int* ctl = reinterpret_cast<int*>(smem + 28 * (size_t)cap);                      // 16 bytes of counters
+    unsigned char* tail = smem + 28 * (size_t)cap + 16;
+    float4* sbox = reinterpret_cast<float4*>(tail);                                  // 16*cap
+    int* scls = reinterpret_cast<int*>(tail + 16 * (size_t)cap);                     // 4*cap
+    int* sidx = reinterpret_cast<int*>(tail + 20 * (size_t)cap);                     // 4*cap
+    float* rawlds = reinterpret_cast<float*>(tail);                                  // fused staging aliases sorted arrays
+    int* kept = reinterpret_cast<int*>(key);
+    unsigned long long* mask = reinterpret_cast<unsigned long long*>(cbox);
+
+    if (tid == 0) { ctl[0] = 0; }
+    __syncthreads();
+
+    // ---- A: filter / decode ----
+    if (FUSED) {
+        const int D = 5 + g.C;
+        const float* rimg = g.raw + n * (int64_t)A * D;
+        for (int b0 = 0; b0 < A; b0 += g.bpc) {
+            const int nb = (A - b0) < g.bpc ? (A - b0) : g.bpc;
+            const int skew = stage_floats(rimg + (int64_t)b0 * D, nb * D, rawlds, tid);
+            __syncthreads();
+            for (int t = tid; t < nb; t += kThreads) {
+                const int bi = b0 + t;
+                const int a = bi % g.A_anch, cell = bi / g.A_anch;
+                Decoded d = decode_one(rawlds + skew + t * D, g.C, cell / g.S, cell % g.S, g.S, g.anchors[2 * a],
+                                       g.anchors[2 * a + 1]);
+                const int64_t o = n * A + bi;
+                g.boxes_out[o] = make_float4(d.x, d.y, d.w, d.h);
+                g.score_out[o] = d.score;
+                g.cls_out[o] = d.cls;
+                if (d.score >= g.score_thr) {
+                    int slot = atomicAdd(&ctl[0], 1);
+                    key[slot] = make_key(d.score, bi);
+                    cbox[slot] = make_float4(d.x - 0.5f * d.w, d.y - 0.5f * d.h, d.x + 0.5f * d.w, d.y + 0.5f * d.h);
+                    ccls[slot] = d.cls;
+                }
+            }
+            __syncthreads();
+        }
+    } else {
+        for (int i = tid; i < A; i += kThreads) {
+            const int64_t o = n * A + i;
+            float s = g.score_in[o];
+            if (s >= g.score_thr) {
+                float4 v = g.boxes_in[o];
+                int slot = atomicAdd(&ctl[0], 1);
+                key[slot] = make_key(s, i);
+                cbox[slot] = make_float4(v.x - 0.5f * v.z, v.y - 0.5f * v.w, v.x + 0.5f * v.z, v.y + 0.5f * v.w);
+                ccls[slot] = g.cls_in[o];
+            }
+        }
+        __syncthreads();
+    }
+    const int K = ctl[0];
+
+    // ---- B: rank sort ----
+    for (int c = tid; c < K; c += kThreads) {
+        const unsigned long long k = key[c];
+        int r = 0;
+        for (int j = 0; j < K; ++j) r += (key[j] < k) ? 1 : 0;
+        sbox[r] = cbox[c];
+        scls[r] = ccls[c];
+        sidx[r] = (int)(unsigned)(k & 0xffffffffull);
+    }
+    __syncthreads();   // key/cbox/ccls are dead from here: kept aliases key, mask aliases cbox
+
+    // ---- C: tiled greedy suppression ----
+    const int W = (K + 63) >> 6;
+    unsigned long long removed = 0;   // wave 0: lane w holds the removed bits of sorted positions 64w..64w+63
+    int nk = 0;
+    for (int b = 0; b < W; ++b) {
+        const int nw = W - b;
+        for (int item = tid; item < 64 * nw; item += kThreads) {
+            const int r = item & 63, wo = item >> 6;
+            const int i = 64 * b + r;
+            unsigned long long m = 0;
+            if (i < K) {
+                const float4 p = sbox[i];
+                const int ci = scls[i];
+                const int jbase = 64 * (b + wo);
+                const int jend = (K - jbase) < 64 ? (K - jbase) : 64;
+                for (int bit = 0; bit < jend; ++bit) {
+                    const int j = jbase + bit;
+                    const float4 q = sbox[j];
+                    const float v = yfs_iou_corners(p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w);
+                    const bool hit = (j > i) && (scls[j] == ci) && (v > g.iou_thr);
+                    m |= hit ? (1ull << bit) : 0ull;
+                }
+            }
+            mask[(size_t)r * nw + wo] = m;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const unsigned long long diag = mask[(size_t)lane * nw];   // row = lane, word b
+            unsigned long long rem_b = __shfl(removed, b, 64);
+            unsigned long long keptbits = 0;
+            const int rows = (K - 64 * b) < 64 ? (K - 64 * b) : 64;
+            for (int r = 0; r < rows; ++r) {
+                const unsigned long long dr = __shfl(diag, r, 64);
+                if (!((rem_b >> r) & 1ull)) {
+                    keptbits |= 1ull << r;
+                    rem_b |= dr;
+                }
+            }
+            // OR the kept rows into this lane's word (lane w covers word w, w in [b, W))
+            if (lane >= b && lane < W) {
+                unsigned long long acc = removed;
+                unsigned long long kb = keptbits;
+                while (kb) {
+                    const int r = __builtin_ctzll(kb);
+                    kb &= kb - 1;
+                    acc |= mask[(size_t)r * nw + (lane - b)];
+                }
+                removed = acc;
+            }
+            if ((keptbits >> lane) & 1ull) {
+                const int pos = nk + __builtin_popcountll(keptbits & ((1ull << lane) - 1ull));
+                kept[pos] = sidx[64 * b + lane];
+            }
+            nk += __builtin_popcountll(keptbits);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) ctl[1] = nk;
+    __syncthreads();
+    nk = ctl[1];
+
+    // ---- D: outputs ----
+    int32_t* kp = g.keep + n * (int64_t)A;
+    for (int i = tid; i < A; i += kThreads) kp[i] = i < nk ? kept[i] : -1;
+    if (tid == 0) g.count[n] = nk;
+}
+
+size_t nms_lds_bytes(int cap, bool fused, int bpc, int D) {
+    size_t head = 28 * (size_t)cap + 16;
+    size_t tail = 24 * (size_t)cap;
+    if (fused) {
+        size_t rawb = ((size_t)bpc * D + 8) * 4;
+        if (rawb > tail) tail = rawb;
+    }
+    return head + tail;
+}
+
+}  // namespace
+
+// =============================== C ABI ========================================================
+YFS_API size_t yfs_iou_xywh_workspace_bytes(int64_t n) {
+    return n > 0 ? (size_t)yfs_cdiv(n, kThreads) * sizeof(float) : 0;
+}
+
+YFS_API int yfs_iou_xywh_f32(const float* pred, const float* gt, int64_t n, float* iou_out, float* mean_out,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+    YFS_REQUIRE(pred && gt && n > 0, YFS_ERR_INVALID_ARG, "yfs_iou_xywh_f32: null input or n <= 0 (n=%lld)", (long long)n);
+    YFS_REQUIRE(iou_out || mean_out, YFS_ERR_INVALID_ARG, "yfs_iou_xywh_f32: no output requested");
+    YFS_REQUIRE(!mean_out || (workspace && workspace_bytes >= yfs_iou_xywh_workspace_bytes(n)), YFS_ERR_WORKSPACE,
+                "yfs_iou_xywh_f32: workspace needs %zu bytes", yfs_iou_xywh_workspace_bytes(n));
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t nblk = yfs_cdiv(n, kThreads);
+    iou_rows_kernel<<<dim3((unsigned)nblk), dim3(kThreads), 0, s>>>((const float4*)pred, (const float4*)gt, n, iou_out,
+                                                                    mean_out ? (float*)workspace : nullptr);
+    YFS_CHECK_LAUNCH("iou_rows_kernel");
+    if (mean_out) {
+        finalize_sum_kernel<<<1, kThreads, 0, s>>>((const float*)workspace, nblk, 1.0f / (float)n, mean_out);
+        YFS_CHECK_LAUNCH("finalize_sum_kernel");
+    }
+    return YFS_OK;
+}
+
+YFS_API int yfs_iou_variant_f32(const float* pred, const float* gt, int64_t n, int variant, float* iou_out,
+                                void* stream) {
+    YFS_REQUIRE(pred && gt && iou_out && n > 0, YFS_ERR_INVALID_ARG, "yfs_iou_variant_f32: null pointer or n <= 0");
+    YFS_REQUIRE(variant >= 0 && variant <= 2, YFS_ERR_INVALID_ARG, "yfs_iou_variant_f32: variant %d not in 0..2", variant);
+    iou_variant_kernel<<<dim3((unsigned)yfs_cdiv(n, kThreads)), dim3(kThreads), 0, (hipStream_t)stream>>>(
+        (const float4*)pred, (const float4*)gt, n, variant, iou_out);
+    YFS_CHECK_LAUNCH("iou_variant_kernel");
+    return YFS_OK;
+}
+
+YFS_API int yfs_pairwise_iou_f32(const float* a, int64_t na, const float* b, int64_t nb, float* out, void* stream) {
+    YFS_REQUIRE(a && b && out && na > 0 && nb > 0, YFS_ERR_INVALID_ARG, "yfs_pairwise_iou_f32: null pointer or empty input");
+    dim3 grid((unsigned)yfs_cdiv(nb, kPairCols), (unsigned)yfs_cdiv(na, 64));
+    YFS_REQUIRE(grid.y <= 65535, YFS_ERR_UNSUPPORTED, "yfs_pairwise_iou_f32: na=%lld too large", (long long)na);
+    pairwise_iou_kernel<<<grid, dim3(kThreads), 0, (hipStream_t)stream>>>((const float4*)a, na, (const float4*)b, nb, out);
+    YFS_CHECK_LAUNCH("pairwise_iou_kernel");
+    return YFS_OK;
+}
+
+YFS_API int yfs_decode_head_f32(const float* t, int64_t n, float prior_w, float prior_h, float* out, void* stream) {
+    YFS_REQUIRE(t && out && n > 0, YFS_ERR_INVALID_ARG, "yfs_decode_head_f32: null pointer or n <= 0");
+    decode_head_kernel<<<dim3((unsigned)yfs_cdiv(n, kThreads)), dim3(kThreads), 0, (hipStream_t)stream>>>(
+        (const float4*)t, n, prior_w, prior_h, (float4*)out);
+    YFS_CHECK_LAUNCH("decode_head_kernel");
+    return YFS_OK;
+}
+
+YFS_API int yfs_decode_xywh_f32(const float* t, int64_t n, float* out, void* stream) {
+    YFS_REQUIRE(t && out && n > 0, YFS_ERR_INVALID_ARG, "yfs_decode_xywh_f32: null pointer or n <= 0");
+    decode_xywh_kernel<<<dim3((unsigned)yfs_cdiv(n, kThreads)), dim3(kThreads), 0, (hipStream_t)stream>>>(
+        (const float4*)t, n, (float4*)out);
+    YFS_CHECK_LAUNCH("decode_xywh_kernel");
+    return YFS_OK;
+}
+
+static int pick_boxes_per_block(int D) {
+    int bpb = kThreads;
+    while ((size_t)bpb * D * 4 > 48 * 1024 && bpb > 32) bpb >>= 1;
+    return bpb;
+}
+
+YFS_API int yfs_decode_grid_f32(const float* raw, int64_t N, int S, int A, int C, const float* anchors, float* boxes,
+                                float* score, int32_t* cls, float* all_scores, void* stream) {
+    YFS_REQUIRE(raw && anchors && boxes && score && cls, YFS_ERR_INVALID_ARG, "yfs_decode_grid_f32: null pointer");
+    YFS_REQUIRE(N > 0 && S > 0 && A > 0 && C > 0 && C <= 1024, YFS_ERR_INVALID_ARG,
+                "yfs_decode_grid_f32: bad shape N=%lld S=%d A=%d C=%d", (long long)N, S, A, C);
+    const int D = 5 + C;
+    const int bpb = pick_boxes_per_block(D);
+    const int64_t nboxes = N * S * S * A;
+    const size_t lds = ((size_t)bpb * D + 8) * 4;
+    decode_grid_kernel<<<dim3((unsigned)yfs_cdiv(nboxes, bpb)), dim3(kThreads), lds, (hipStream_t)stream>>>(
+        raw, nboxes, S, A, C, anchors, bpb, (float4*)boxes, score, cls, all_scores);
+    YFS_CHECK_LAUNCH("decode_grid_kernel");
+    return YFS_OK;
+}
+
+YFS_API int yfs_decode_v1_f32(const float* pred, int64_t N, int S, int B, int C, float* boxes, float* score,
+                              int32_t* cls, void* stream) {
+    YFS_REQUIRE(pred && boxes && score && cls, YFS_ERR_INVALID_ARG, "yfs_decode_v1_f32: null pointer");
+    YFS_REQUIRE(N > 0 && S > 0 && B > 0 && C > 0 && (5 * B + C) <= 40, YFS_ERR_INVALID_ARG,
+                "yfs_decode_v1_f32: bad shape N=%lld S=%d B=%d C=%d (5B+C <= 40)", (long long)N, S, B, C);
+    const int D = 5 * B + C;
+    const int64_t ncells = N * S * S;
+    const size_t lds = ((size_t)kThreads * D + 8) * 4;
+    decode_v1_kernel<<<dim3((unsigned)yfs_cdiv(ncells, kThreads)), dim3(kThreads), lds, (hipStream_t)stream>>>(
+        pred, ncells, S, B, C, (float4*)boxes, score, cls);
+    YFS_CHECK_LAUNCH("decode_v1_kernel");
+    return YFS_OK;
+}
+
+YFS_API int yfs_nms_classwise_f32(const float* boxes, const float* score, const int32_t* cls, int64_t N, int A,
+                                  float score_thr, float iou_thr, int32_t* keep, int32_t* count, void* stream) {
+    YFS_REQUIRE(boxes && score && cls && keep && count, YFS_ERR_INVALID_ARG, "yfs_nms_classwise_f32: null pointer");
+    YFS_REQUIRE(N > 0 && A > 0, YFS_ERR_INVALID_ARG, "yfs_nms_classwise_f32: bad shape N=%lld A=%d", (long long)N, A);
+    YFS_REQUIRE(A <= YFS_NMS_MAX_BOXES, YFS_ERR_UNSUPPORTED, "yfs_nms_classwise_f32: A=%d exceeds %d boxes per image", A,
+                YFS_NMS_MAX_BOXES);
+    NmsArgs g = {};
+    g.boxes_in = (const float4*)boxes; g.score_in = score; g.cls_in = cls;
+    g.keep = keep; g.count = count; g.A = A; g.cap = (A + 63) & ~63;
+    g.score_thr = score_thr; g.iou_thr = iou_thr;
+    const size_t lds = nms_lds_bytes(g.cap, false, 0, 0);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)nms_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        YFS_REQUIRE(e == hipSuccess, YFS_ERR_LAUNCH, "yfs_nms_classwise_f32: cannot reserve %zu bytes of LDS", lds);
+    }
+    nms_kernel<false><<<dim3((unsigned)N), dim3(kThreads), lds, (hipStream_t)stream>>>(g);
+    YFS_CHECK_LAUNCH("nms_kernel");
+    return YFS_OK;
+}
+
+YFS_API int yfs_decode_nms_f32(const float* raw, int64_t N, int S, int A, int C, const float* anchors, float score_thr,
+                               float iou_thr, float* boxes, float* score, int32_t* cls, int32_t* keep, int32_t* count,
+                               void* stream) {
+    YFS_REQUIRE(raw && anchors && boxes && score && cls && keep && count, YFS_ERR_INVALID_ARG, "yfs_decode_nms_f32: null pointer");
+    YFS_REQUIRE(N > 0 && S > 0 && A > 0 && C > 0 && C <= 1024, YFS_ERR_INVALID_ARG,
+                "yfs_decode_nms_f32: bad shape N=%lld S=%d A=%d C=%d", (long long)N, S, A, C);
+    const int64_t per = (int64_t)S * S * A;
+    YFS_REQUIRE(per <= YFS_NMS_MAX_BOXES, YFS_ERR_UNSUPPORTED, "yfs_decode_nms_f32: %lld boxes per image exceeds %d",
+                (long long)per, YFS_NMS_MAX_BOXES);
+    NmsArgs g = {};
+    g.raw = raw; g.anchors = anchors; g.S = S; g.A_anch = A; g.C = C;
+    g.boxes_out = (float4*)boxes; g.score_out = score; g.cls_out = cls;
+    g.keep = keep; g.count = count; g.A = (int)per; g.cap = ((int)per + 63) & ~63;
+    g.bpc = pick_boxes_per_block(5 + C);
+    g.score_thr = score_thr; g.iou_thr = iou_thr;
+    const size_t lds = nms_lds_bytes(g.cap, true, g.bpc, 5 + C);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)nms_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        YFS_REQUIRE(e == hipSuccess, YFS_ERR_LAUNCH, "yfs_decode_nms_f32: cannot reserve %zu bytes of LDS", lds);
+    }
+    nms_kernel<true><<<dim3((unsigned)N), dim3(kThreads), lds, (hipStream_t)stream>>>(g);
+    YFS_CHECK_LAUNCH("nms_kernel<fused>");
+    return YFS_OK;
+}
