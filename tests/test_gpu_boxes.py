@@ -141,8 +141,10 @@ def test_fused_decode_nms(N, S, A, C):
     keep_o, cnt_o = oracle.nms(b, s, c, 0.05, 0.5)
     np.testing.assert_array_equal(cnt, cnt_o)
     np.testing.assert_array_equal(keep, keep_o)
+    # SURVEY.md §8(d) guessed 10-15 % of boxes pass score_thr with the -1 objectness shift; the literal
+    # config (N(0,1) logits, shift -1) passes ~53 %, i.e. ~450 NMS candidates per image.
     frac = (s >= 0.05).mean()
-    assert 0.02 < frac < 0.5
+    assert 0.02 < frac < 0.9
 
 
 def test_config4_full_size_properties():
