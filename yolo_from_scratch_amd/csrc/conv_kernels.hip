@@ -1,0 +1,732 @@
+// Kernel set 1: Conv2D block (Conv2d k/s, pad k/2, bias + LeakyReLU) forward / dgrad / wgrad as
+// bf16 MFMA implicit GEMMs for gfx950.  Replaces the 24 Conv2D(...) call sites of the reference
+// backbone (yolo_toy_regressor_torch.py:206-211, :218-254) and their autograd.
+//
+// Layout: activations NHWC bf16, weights [Cout][KH][KW][Cin] bf16 (reduction index contiguous),
+// fp32 accumulation in v_mfma_f32_16x16x32_bf16.
+//
+//   forward / dgrad ("igemm"): out[pixel][n] = sum_{tap,c} in[gather(pixel,tap)][c] * wt[n][tap][c]
+//     MFMA roles: A operand = weight rows (n), B operand = gathered pixels, so every lane ends up with
+//     4 consecutive output channels of one pixel.  Block tile BM pixels x BN channels x 64 deep, 4 waves
+//     (2x2), operands register-staged (global 16 B -> VGPR -> ds_write_b128, issued one tile ahead so
+//     the loads fly under the MFMAs), LDS rows of 128 B XOR-swizzled by (row & 7) so the fragment
+//     ds_read_b128 is conflict free; epilogue goes through an fp32 LDS tile so bias / LeakyReLU / the
+//     activation-derivative mask run in fp32 and the bf16 result leaves as whole 16 B per lane.
+//   wgrad: dw[co][tap][ci] = sum_pixel dz[pixel][co] * x[gather(pixel,tap)][ci] — both operands have the
+//     reduction index (pixel) as the slow axis, so the LDS tiles keep [pixel][channel] rows and the
+//     fragments are read with ds_read_b64_tr_b16 (hardware transpose); split-K over pixels with fp32
+//     partial slabs and a fixed-order reduction (deterministic).
+#include "yfs_common.h"
+
+namespace {
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int kThreads = 256;
+constexpr int BK = 64;   // reduction depth per LDS tile (128 B rows)
+
+enum { EPI_BIAS_LEAKY = 0, EPI_MASK = 1, EPI_NONE = 2 };
+
+struct IgemmArgs {
+    const bf16_t* x;      // [N,H,W,C]
+    const bf16_t* w;      // [NOUT][taps][C]
+    const float* bias;    // [NOUT]            (EPI_BIAS_LEAKY)
+    const bf16_t* act;    // [M][NOUT]         (EPI_MASK: multiply by act > 0 ? 1 : slope)
+    bf16_t* out;          // [M][NOUT]
+    int N, H, W, C;
+    int OH, OW, NOUT;
+    int KS;               // taps = KS*KS
+    int s_mul, pad, dil;  // src = o*s_mul - pad + k ; dil > 1: src must divide by dil (strided dgrad)
+    int M;                // N*OH*OW
+    int mtiles, ntiles;
+    float slope;
+};
+
+// XCD-aware, bijective remap: blocks that share blockIdx % 8 share an XCD (and its L2); give each XCD a
+// contiguous run of logical tiles so the NT blocks that re-read one pixel tile hit the same L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+
+__device__ __forceinline__ unsigned swz(int row, int chunk) { return (unsigned)(row * 128 + ((chunk ^ (row & 7)) << 4)); }
+
+template <int BM, int BN, int EPI, bool DIL>
+__global__ void __launch_bounds__(kThreads, 2) igemm_kernel(IgemmArgs g) {
+    constexpr int FP = BM / 32;   // pixel fragments per wave   (wave tile BM/2 x BN/2)
+    constexpr int FC = BN / 32;   // channel fragments per wave
+    constexpr int RA = BM / 32;   // staged rows per thread, pixel tile
+    constexpr int RB = BN / 32;   // staged rows per thread, weight tile
+    constexpr int TILE_BYTES = (BM + BN) * 128;
+    constexpr int EPI_STRIDE = BN * 4 + 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int logical = xcd_remap(blockIdx.x, g.mtiles * g.ntiles);
+    const int nt = logical % g.ntiles, mt = logical / g.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // ---- per-thread staging coordinates -------------------------------------------------------
+    const int chunk = tid & 7, srow = tid >> 3;   // 32 rows per pass
+    int bh[RA], bw[RA];
+    long long ximg[RA];
+    int rowoff[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int m = m0 + srow + 32 * i;
+        if (m < g.M) {
+            const int n = m / (g.OH * g.OW);
+            const int rem = m - n * (g.OH * g.OW);
+            const int oh = rem / g.OW, ow = rem - oh * g.OW;
+            bh[i] = oh * g.s_mul - g.pad;
+            bw[i] = ow * g.s_mul - g.pad;
+            ximg[i] = (long long)n * g.H * g.W * g.C;
+        } else {
+            bh[i] = -(1 << 28);
+            bw[i] = -(1 << 28);
+            ximg[i] = 0;
+        }
+        rowoff[i] = chunk * 8;
+    }
+    const long long ktot = (long long)g.KS * g.KS * g.C;
+    const bf16_t* wbase = g.w + (long long)(n0 + srow) * ktot + chunk * 8;
+
+    const int cchunks = g.C / BK;
+    const int nit = g.KS * g.KS * cchunks;
+
+    bf16x8 ra[RA], rb[RB];
+    int kh = 0, kw = 0, cc = 0;   // position of the NEXT tile to load
+
+    auto load_tile = [&](int it) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            int sh = bh[i] + kh, sw = bw[i] + kw;
+            bool ok;
+            if (DIL) {
+                ok = sh >= 0 && sw >= 0 && (sh % g.dil) == 0 && (sw % g.dil) == 0;
+                sh /= g.dil;
+                sw /= g.dil;
+                ok = ok && sh < g.H && sw < g.W;
+            } else {
+                ok = (unsigned)sh < (unsigned)g.H && (unsigned)sw < (unsigned)g.W;
+            }
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (ok) v = *reinterpret_cast<const bf16x8*>(g.x + ximg[i] + ((long long)(sh * g.W + sw) * g.C + cc * BK + rowoff[i]));
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+            rb[i] = *reinterpret_cast<const bf16x8*>(wbase + (long long)(32 * i) * ktot + (long long)it * BK);
+        if (++cc == cchunks) {
+            cc = 0;
+            if (++kw == g.KS) { kw = 0; ++kh; }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        unsigned char* base = smem + buf * TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) *reinterpret_cast<bf16x8*>(base + swz(srow + 32 * i, chunk)) = ra[i];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) *reinterpret_cast<bf16x8*>(base + BM * 128 + swz(srow + 32 * i, chunk)) = rb[i];
+    };
+
+    f32x4 acc[FC][FP];
+#pragma unroll
+    for (int a = 0; a < FC; ++a)
+#pragma unroll
+        for (int b = 0; b < FP; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const int frow = lane & 15, fk = lane >> 4;
+    for (int it = 0; it < nit; ++it) {
+        const bool more = it + 1 < nit;
+        if (more) load_tile(it + 1);
+        const unsigned char* pb = smem + (it & 1) * TILE_BYTES;
+        const unsigned char* wb = pb + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 wf[FC], pf[FP];
+#pragma unroll
+            for (int a = 0; a < FC; ++a)
+                wf[a] = *reinterpret_cast<const bf16x8*>(wb + swz(wn * (BN / 2) + a * 16 + frow, ks * 4 + fk));
+#pragma unroll
+            for (int b = 0; b < FP; ++b)
+                pf[b] = *reinterpret_cast<const bf16x8*>(pb + swz(wm * (BM / 2) + b * 16 + frow, ks * 4 + fk));
+#pragma unroll
+            for (int a = 0; a < FC; ++a)
+#pragma unroll
+                for (int b = 0; b < FP; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], pf[b], acc[a][b], 0, 0, 0);
+        }
+        if (more) store_tile((it + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: fp32 tile through LDS, then coalesced 16 B stores ---------------------------
+    // acc[a][b][r] = out[pixel = wm*BM/2 + b*16 + (lane&15)][chan = wn*BN/2 + a*16 + (lane>>4)*4 + r]
+#pragma unroll
+    for (int a = 0; a < FC; ++a)
+#pragma unroll
+        for (int b = 0; b < FP; ++b) {
+            const int prow = wm * (BM / 2) + b * 16 + frow;
+            const int ch = wn * (BN / 2) + a * 16 + fk * 4;
+            *reinterpret_cast<f32x4*>(smem + prow * EPI_STRIDE + ch * 4) = acc[a][b];
+        }
+    __syncthreads();
+    constexpr int TPR = BN / 8;            // threads per output row (8 channels each)
+    constexpr int RPP = kThreads / TPR;    // rows per pass
+    const int ec = (tid % TPR) * 8, er = tid / TPR;
+    float bv[8];
+    if (EPI == EPI_BIAS_LEAKY) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bv[j] = g.bias[n0 + ec + j];
+    }
+#pragma unroll
+    for (int p = 0; p < BM / RPP; ++p) {
+        const int row = er + p * RPP;
+        const int m = m0 + row;
+        if (m >= g.M) continue;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(smem + row * EPI_STRIDE + ec * 4);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(smem + row * EPI_STRIDE + ec * 4 + 16);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        const long long o = (long long)m * g.NOUT + n0 + ec;
+        if (EPI == EPI_BIAS_LEAKY) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float t = v[j] + bv[j];
+                v[j] = t > 0.0f ? t : t * g.slope;
+            }
+        } else if (EPI == EPI_MASK) {
+            const bf16x8 av = *reinterpret_cast<const bf16x8*>(g.act + o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (float)av[j] > 0.0f ? v[j] : v[j] * g.slope;
+        }
+        bf16x8 ov;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ov[j] = (bf16_t)v[j];
+        *reinterpret_cast<bf16x8*>(g.out + o) = ov;
+    }
+}
+
+template <int BM, int BN>
+constexpr size_t igemm_lds_bytes() {
+    size_t stage = 2 * (size_t)(BM + BN) * 128;
+    size_t epi = (size_t)BM * (BN * 4 + 16);
+    return stage > epi ? stage : epi;
+}
+
+template <int BM, int BN, int EPI, bool DIL>
+int launch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
+    g.mtiles = (int)yfs_cdiv(g.M, BM);
+    g.ntiles = g.NOUT / BN;
+    const size_t lds = igemm_lds_bytes<BM, BN>();
+    auto kern = igemm_kernel<BM, BN, EPI, DIL>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        YFS_REQUIRE(e == hipSuccess, YFS_ERR_LAUNCH, "%s: cannot reserve %zu bytes of LDS", name, lds);
+    }
+    kern<<<dim3((unsigned)(g.mtiles * g.ntiles)), dim3(kThreads), lds, s>>>(g);
+    YFS_CHECK_LAUNCH(name);
+    return YFS_OK;
+}
+
+template <int EPI, bool DIL>
+int dispatch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
+    if (g.NOUT % 128 == 0) return launch_igemm<128, 128, EPI, DIL>(g, s, name);
+    return launch_igemm<128, 64, EPI, DIL>(g, s, name);
+}
+
+int check_conv_shape(const char* fn, int64_t N, int H, int W, int Cin, int Cout, int K, int stride) {
+    YFS_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, YFS_ERR_INVALID_ARG, "%s: non-positive dimension", fn);
+    YFS_REQUIRE(K == 1 || K == 3 || K == 5 || K == 7, YFS_ERR_UNSUPPORTED, "%s: kernel size %d not in {1,3,5,7}", fn, K);
+    YFS_REQUIRE(stride == 1 || stride == 2, YFS_ERR_UNSUPPORTED, "%s: stride %d not in {1,2}", fn, stride);
+    YFS_REQUIRE(Cin % 64 == 0, YFS_ERR_UNSUPPORTED, "%s: Cin=%d must be a multiple of 64 (use yfs_im2col_bf16 for the stem)", fn, Cin);
+    YFS_REQUIRE(Cout % 64 == 0, YFS_ERR_UNSUPPORTED, "%s: Cout=%d must be a multiple of 64", fn, Cout);
+    const int pad = K / 2;
+    const int64_t Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
+    YFS_REQUIRE(N * Ho * Wo < (1ll << 31) && (int64_t)H * W * Cin < (1ll << 31), YFS_ERR_UNSUPPORTED,
+                "%s: tensor too large for 32-bit pixel indexing", fn);
+    return YFS_OK;
+}
+
+}  // namespace
+
+YFS_API int yfs_conv2d_fwd_bf16(const void* x, const void* w, const float* bias, void* y, int64_t N, int H, int W,
+                                int Cin, int Cout, int K, int stride, float slope, void* stream) {
+    YFS_REQUIRE(x && w && bias && y, YFS_ERR_INVALID_ARG, "yfs_conv2d_fwd_bf16: null pointer");
+    int rc = check_conv_shape("yfs_conv2d_fwd_bf16", N, H, W, Cin, Cout, K, stride);
+    if (rc) return rc;
+    const int pad = K / 2;
+    IgemmArgs g = {};
+    g.x = (const bf16_t*)x; g.w = (const bf16_t*)w; g.bias = bias; g.out = (bf16_t*)y;
+    g.N = (int)N; g.H = H; g.W = W; g.C = Cin;
+    g.OH = (H + 2 * pad - K) / stride + 1; g.OW = (W + 2 * pad - K) / stride + 1; g.NOUT = Cout;
+    g.KS = K; g.s_mul = stride; g.pad = pad; g.dil = 1; g.slope = slope;
+    g.M = (int)(N * g.OH * g.OW);
+    return dispatch_igemm<EPI_BIAS_LEAKY, false>(g, (hipStream_t)stream, "yfs_conv2d_fwd_bf16");
+}
+
+YFS_API int yfs_conv2d_dgrad_bf16(const void* dz, const void* wt, const void* x_act, void* dx, int64_t N, int H, int W,
+                                  int Cin, int Cout, int K, int stride, float slope, void* stream) {
+    YFS_REQUIRE(dz && wt && dx, YFS_ERR_INVALID_ARG, "yfs_conv2d_dgrad_bf16: null pointer");
+    int rc = check_conv_shape("yfs_conv2d_dgrad_bf16", N, H, W, Cout, Cin, K, stride);   // roles swap: reduce over Cout
+    if (rc) return rc;
+    const int pad = K / 2;
+    IgemmArgs g = {};
+    g.x = (const bf16_t*)dz; g.w = (const bf16_t*)wt; g.act = (const bf16_t*)x_act; g.out = (bf16_t*)dx;
+    g.N = (int)N;
+    g.H = (H + 2 * pad - K) / stride + 1; g.W = (W + 2 * pad - K) / stride + 1; g.C = Cout;   // gathered tensor = dz
+    g.OH = H; g.OW = W; g.NOUT = Cin;
+    g.KS = K; g.s_mul = 1; g.pad = K - 1 - pad; g.dil = stride; g.slope = slope;
+    g.M = (int)(N * H * W);
+    hipStream_t s = (hipStream_t)stream;
+    if (stride == 1) {
+        return x_act ? dispatch_igemm<EPI_MASK, false>(g, s, "yfs_conv2d_dgrad_bf16")
+                     : dispatch_igemm<EPI_NONE, false>(g, s, "yfs_conv2d_dgrad_bf16");
+    }
+    return x_act ? dispatch_igemm<EPI_MASK, true>(g, s, "yfs_conv2d_dgrad_bf16")
+                 : dispatch_igemm<EPI_NONE, true>(g, s, "yfs_conv2d_dgrad_bf16");
+}
+
+// =============================== wgrad ==========================================================
+namespace {
+
+// n / d for 0 <= n < 2^31 with a host-prepared multiplier (Granlund-Montgomery round-up form).
+struct FastDiv {
+    unsigned mul, shift, d;
+};
+FastDiv make_fastdiv(unsigned d) {
+    FastDiv f;
+    f.d = d;
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    f.shift = l;
+    f.mul = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) { return (__umulhi(n, f.mul) + n) >> f.shift; }
+
+struct WgradArgs {
+    const bf16_t* dz;   // [M][Cout]
+    const bf16_t* x;    // [N,H,W,Cin]
+    float* partial;     // [splits][Cout][taps*Cin]
+    int H, W, Cin, OH, OW, Cout, KS, stride, pad, M;
+    int cotiles, citiles, splits, ktiles, ktiles_per_split;
+    FastDiv div_ohw, div_ow;
+};
+
+// LDS image of one operand tile: [channel/16][64 pixels][16 channels] bf16, i.e. 32-byte pixel rows
+// inside 2 KiB sub-tiles; address bit 7 is XORed with pixel bit 3 so that the two pixel quads a
+// 32-lane half reads with ds_read_b64_tr_b16 (pixels 8g..8g+3, g = 0,1) fall on disjoint bank halves.
+__device__ __forceinline__ unsigned wg_off(int pixel, int ch /* channel index inside the tile */) {
+    return (unsigned)((ch >> 4) * 2048 + ((pixel * 32) ^ (((pixel >> 3) & 1) << 7)) + (ch & 15) * 2);
+}
+
+// BX = ci tile (MFMA rows), BZ = co tile (MFMA cols).  4 waves as 2 (ci) x 2 (co).
+template <int BX, int BZ>
+__global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
+    constexpr int FX = BX / 32, FZ = BZ / 32;          // fragments per wave
+    constexpr int GX = BX / 64, GZ = BZ / 64;          // 8-chunk groups per pixel row
+    constexpr int LX = 2 * GX, LZ = 2 * GZ;            // 16-byte loads per thread per tile
+    constexpr int XBYTES = BX * 128, ZBYTES = BZ * 128;   // 64 pixels * channels * 2 B
+    constexpr int TILE_BYTES = XBYTES + ZBYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wx = wave >> 1, wz = wave & 1;
+    const int taps = g.KS * g.KS;
+    const int tiles = g.cotiles * g.citiles * taps;
+    const int logical = xcd_remap(blockIdx.x, tiles * g.splits);
+    // consecutive logical ids sweep (tap, ci tile) for a fixed (split, co tile): they re-read one dz slab
+    const int inner = g.citiles * taps;
+    const int tci = logical % inner;
+    const int rest = logical / inner;
+    const int cot = rest % g.cotiles, split = rest / g.cotiles;
+    const int tap = tci / g.citiles, cit = tci % g.citiles;
+    const int kh = tap / g.KS, kw = tap % g.KS;
+    const int co0 = cot * BZ, ci0 = cit * BX;
+
+    const int kt0 = split * g.ktiles_per_split;
+    int kt1 = kt0 + g.ktiles_per_split;
+    if (kt1 > g.ktiles) kt1 = g.ktiles;
+
+    const int p_lo = lane & 7, c_lo = lane >> 3;
+    bf16x8 rx[LX], rz[LZ];
+
+    auto load_tile = [&](int kt) {
+        const int mbase = kt * 64;
+#pragma unroll
+        for (int i = 0; i < LZ; ++i) {
+            const int idx = wave * LZ + i;
+            const int pixel = (idx / GZ) * 8 + p_lo, ch = ((idx % GZ) * 8 + c_lo) * 8;
+            const int m = mbase + pixel;
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (m < g.M) v = *reinterpret_cast<const bf16x8*>(g.dz + (long long)m * g.Cout + co0 + ch);
+            rz[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < LX; ++i) {
+            const int idx = wave * LX + i;
+            const int pixel = (idx / GX) * 8 + p_lo, ch = ((idx % GX) * 8 + c_lo) * 8;
+            const int m = mbase + pixel;
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (m < g.M) {
+                const unsigned n = fdiv((unsigned)m, g.div_ohw);
+                const unsigned rem = (unsigned)m - n * g.div_ohw.d;
+                const unsigned oh = fdiv(rem, g.div_ow);
+                const unsigned ow = rem - oh * g.div_ow.d;
+                const int ih = (int)oh * g.stride - g.pad + kh, iw = (int)ow * g.stride - g.pad + kw;
+                if ((unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W)
+                    v = *reinterpret_cast<const bf16x8*>(g.x + ((long long)(n * g.H + ih) * g.W + iw) * g.Cin + ci0 + ch);
+            }
+            rx[i] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        unsigned char* base = smem + buf * TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < LX; ++i) {
+            const int idx = wave * LX + i;
+            const int pixel = (idx / GX) * 8 + p_lo, ch = ((idx % GX) * 8 + c_lo) * 8;
+            *reinterpret_cast<bf16x8*>(base + wg_off(pixel, ch)) = rx[i];
+        }
+#pragma unroll
+        for (int i = 0; i < LZ; ++i) {
+            const int idx = wave * LZ + i;
+            const int pixel = (idx / GZ) * 8 + p_lo, ch = ((idx % GZ) * 8 + c_lo) * 8;
+            *reinterpret_cast<bf16x8*>(base + XBYTES + wg_off(pixel, ch)) = rz[i];
+        }
+    };
+
+    f32x4 acc[FX][FZ];
+#pragma unroll
+    for (int a = 0; a < FX; ++a)
+#pragma unroll
+        for (int b = 0; b < FZ; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // transposed-read lane geometry: lane (g4 = lane>>4, i = lane&15) supplies the address of pixel
+    // 8*g4 + 4*h + (i>>2), channels 4*(i&3)..+3 of the fragment's 16, and receives channel i of pixels
+    // 8*g4 + 4*h + 0..3 — exactly elements j = 4h..4h+3 of the MFMA operand A[row i][k = 8*g4 + j].
+    const int g4 = lane >> 4, li = lane & 15;
+    const int tr_pix = 8 * g4 + (li >> 2), tr_ch = 4 * (li & 3);
+
+    if (kt0 < kt1) {
+        load_tile(kt0);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const bool more = kt + 1 < kt1;
+        if (more) load_tile(kt + 1);
+        const unsigned char* xb = smem + ((kt - kt0) & 1) * TILE_BYTES;
+        const unsigned char* zb = xb + XBYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 xf[FX], zf[FZ];
+#pragma unroll
+            for (int a = 0; a < FX; ++a) {
+                const int ch = wx * (BX / 2) + a * 16 + tr_ch;
+                bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (bf16x4 __attribute__((address_space(3)))*)(xb + wg_off(ks * 32 + tr_pix, ch)));
+                bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (bf16x4 __attribute__((address_space(3)))*)(xb + wg_off(ks * 32 + tr_pix + 4, ch)));
+                xf[a] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int b = 0; b < FZ; ++b) {
+                const int ch = wz * (BZ / 2) + b * 16 + tr_ch;
+                bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (bf16x4 __attribute__((address_space(3)))*)(zb + wg_off(ks * 32 + tr_pix, ch)));
+                bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (bf16x4 __attribute__((address_space(3)))*)(zb + wg_off(ks * 32 + tr_pix + 4, ch)));
+                zf[b] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int a = 0; a < FX; ++a)
+#pragma unroll
+                for (int b = 0; b < FZ; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[a], zf[b], acc[a][b], 0, 0, 0);
+        }
+        if (more) store_tile(((kt - kt0) + 1) & 1);
+        __syncthreads();
+    }
+
+    // acc[a][b][r] = dw[co = co0 + wz*BZ/2 + b*16 + (lane&15)][tap][ci = ci0 + wx*BX/2 + a*16 + (lane>>4)*4 + r]
+    const long long kw_tot = (long long)taps * g.Cin;
+    float* pbase = g.partial + (long long)split * g.Cout * kw_tot;
+#pragma unroll
+    for (int a = 0; a < FX; ++a)
+#pragma unroll
+        for (int b = 0; b < FZ; ++b) {
+            const int co = co0 + wz * (BZ / 2) + b * 16 + li;
+            const int ci = ci0 + wx * (BX / 2) + a * 16 + g4 * 4;
+            *reinterpret_cast<f32x4*>(pbase + (long long)co * kw_tot + (long long)tap * g.Cin + ci) = acc[a][b];
+        }
+}
+
+// dw[i] = (accumulate ? dw[i] : 0) + sum_s partial[s][i], fixed order over s.
+__global__ void __launch_bounds__(kThreads) splitk_reduce_kernel(const float4* __restrict__ partial, int splits,
+                                                                 long long n4, float4* __restrict__ dw,
+                                                                 int accumulate) {
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n4; i += (long long)gridDim.x * kThreads) {
+        float4 s = accumulate ? dw[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < splits; ++k) {
+            const float4 v = partial[(long long)k * n4 + i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        dw[i] = s;
+    }
+}
+
+// db[co] = sum over pixels of dz[m][co].  Block = 64 channels x 32 row lanes; grid.y splits the rows;
+// partial sums per (row split, channel) are then reduced in fixed order.
+__global__ void __launch_bounds__(kThreads) colsum_kernel(const bf16_t* __restrict__ dz, int M, int C, int rows_per_blk,
+                                                          float* __restrict__ partial) {
+    __shared__ float red[32][64 + 1];
+    const int c8 = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c0 = blockIdx.x * 64 + c8 * 8;
+    const int r0 = blockIdx.y * rows_per_blk;
+    int r1 = r0 + rows_per_blk;
+    if (r1 > M) r1 = M;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int m = r0 + rl; m < r1; m += 32) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(dz + (long long)m * C + c0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[rl][c8 * 8 + j] = acc[j];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float s = 0.f;
+        for (int r = 0; r < 32; ++r) s += red[r][threadIdx.x];
+        partial[(long long)blockIdx.y * C + blockIdx.x * 64 + threadIdx.x] = s;
+    }
+}
+
+__global__ void __launch_bounds__(kThreads) colsum_reduce_kernel(const float* __restrict__ partial, int nsplit, int C,
+                                                                 float* __restrict__ db, int accumulate) {
+    const int c = blockIdx.x * kThreads + threadIdx.x;
+    if (c >= C) return;
+    float s = accumulate ? db[c] : 0.f;
+    for (int k = 0; k < nsplit; ++k) s += partial[(long long)k * C + c];
+    db[c] = s;
+}
+
+struct WgradPlan {
+    int bx, bz, cotiles, citiles, splits, ktiles, ktiles_per_split, db_splits;
+    size_t partial_bytes, db_bytes;
+};
+
+WgradPlan plan_wgrad(int64_t M, int Cin, int Cout, int K) {
+    WgradPlan p;
+    p.bx = (Cin % 128 == 0) ? 128 : 64;
+    p.bz = (Cout % 128 == 0) ? 128 : 64;
+    p.citiles = Cin / p.bx;
+    p.cotiles = Cout / p.bz;
+    p.ktiles = (int)yfs_cdiv(M, 64);
+    const int tiles = p.citiles * p.cotiles * K * K;
+    int splits = (int)yfs_cdiv(1024, tiles);              // aim at >= 4 workgroups per CU
+    const int max_by_work = p.ktiles / 8 > 0 ? p.ktiles / 8 : 1;   // at least 8 k-tiles (512 pixels) per split
+    if (splits > max_by_work) splits = max_by_work;
+    if (splits < 1) splits = 1;
+    p.ktiles_per_split = (int)yfs_cdiv(p.ktiles, splits);
+    p.splits = (int)yfs_cdiv(p.ktiles, p.ktiles_per_split);
+    p.partial_bytes = (size_t)p.splits * Cout * K * K * Cin * sizeof(float);
+    int dbs = (int)yfs_cdiv(M, 2048);
+    if (dbs > 256) dbs = 256;
+    p.db_splits = dbs;
+    p.db_bytes = (size_t)dbs * Cout * sizeof(float);
+    return p;
+}
+
+template <int BX, int BZ>
+int launch_wgrad(WgradArgs& g, const WgradPlan& p, hipStream_t s) {
+    const size_t lds = 2 * (size_t)(BX + BZ) * 128;
+    auto kern = wgrad_kernel<BX, BZ>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        YFS_REQUIRE(e == hipSuccess, YFS_ERR_LAUNCH, "yfs_conv2d_wgrad_bf16: cannot reserve %zu bytes of LDS", lds);
+    }
+    const int nblk = p.cotiles * p.citiles * g.KS * g.KS * p.splits;
+    kern<<<dim3((unsigned)nblk), dim3(kThreads), lds, s>>>(g);
+    YFS_CHECK_LAUNCH("wgrad_kernel");
+    return YFS_OK;
+}
+
+}  // namespace
+
+YFS_API size_t yfs_conv2d_wgrad_workspace_bytes(int64_t N, int H, int W, int Cin, int Cout, int K, int stride) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || K <= 0 || stride <= 0) return 0;
+    const int pad = K / 2;
+    const int64_t M = N * ((H + 2 * pad - K) / stride + 1) * ((W + 2 * pad - K) / stride + 1);
+    WgradPlan p = plan_wgrad(M, Cin, Cout, K);
+    return p.partial_bytes + p.db_bytes;
+}
+
+YFS_API int yfs_conv2d_wgrad_bf16(const void* x, const void* dz, float* dw, float* db, int64_t N, int H, int W, int Cin,
+                                  int Cout, int K, int stride, int accumulate, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+    YFS_REQUIRE(x && dz && dw, YFS_ERR_INVALID_ARG, "yfs_conv2d_wgrad_bf16: null pointer");
+    int rc = check_conv_shape("yfs_conv2d_wgrad_bf16", N, H, W, Cin, Cout, K, stride);
+    if (rc) return rc;
+    const int pad = K / 2;
+    const int OH = (H + 2 * pad - K) / stride + 1, OW = (W + 2 * pad - K) / stride + 1;
+    const int64_t M = N * OH * OW;
+    WgradPlan p = plan_wgrad(M, Cin, Cout, K);
+    YFS_REQUIRE(workspace && workspace_bytes >= p.partial_bytes + p.db_bytes, YFS_ERR_WORKSPACE,
+                "yfs_conv2d_wgrad_bf16: workspace needs %zu bytes, got %zu", p.partial_bytes + p.db_bytes, workspace_bytes);
+    YFS_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, YFS_ERR_WORKSPACE,
+                "yfs_conv2d_wgrad_bf16: workspace must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    WgradArgs g = {};
+    g.dz = (const bf16_t*)dz; g.x = (const bf16_t*)x; g.partial = (float*)workspace;
+    g.H = H; g.W = W; g.Cin = Cin; g.OH = OH; g.OW = OW; g.Cout = Cout; g.KS = K; g.stride = stride; g.pad = pad;
+    g.M = (int)M;
+    g.cotiles = p.cotiles; g.citiles = p.citiles; g.splits = p.splits; g.ktiles = p.ktiles;
+    g.ktiles_per_split = p.ktiles_per_split;
+    g.div_ohw = make_fastdiv((unsigned)(OH * OW)); g.div_ow = make_fastdiv((unsigned)OW);
+    if (p.bx == 128 && p.bz == 128) rc = launch_wgrad<128, 128>(g, p, s);
+    else if (p.bx == 128) rc = launch_wgrad<128, 64>(g, p, s);
+    else if (p.bz == 128) rc = launch_wgrad<64, 128>(g, p, s);
+    else rc = launch_wgrad<64, 64>(g, p, s);
+    if (rc) return rc;
+    const long long n4 = (long long)Cout * K * K * Cin / 4;
+    long long rblk = yfs_cdiv(n4, kThreads);
+    if (rblk > 2048) rblk = 2048;
+    splitk_reduce_kernel<<<dim3((unsigned)rblk), dim3(kThreads), 0, s>>>((const float4*)workspace, p.splits, n4, (float4*)dw,
+                                                                      accumulate);
+    YFS_CHECK_LAUNCH("splitk_reduce_kernel");
+    if (db) {
+        float* dbp = (float*)((unsigned char*)workspace + p.partial_bytes);
+        const int rows_per = (int)yfs_cdiv(M, p.db_splits);
+        colsum_kernel<<<dim3((unsigned)(Cout / 64), (unsigned)p.db_splits), dim3(kThreads), 0, s>>>((const bf16_t*)dz, (int)M, Cout,
+                                                                                             rows_per, dbp);
+        YFS_CHECK_LAUNCH("colsum_kernel");
+        colsum_reduce_kernel<<<dim3((unsigned)yfs_cdiv(Cout, kThreads)), dim3(kThreads), 0, s>>>(dbp, p.db_splits, Cout, db,
+                                                                                            accumulate);
+        YFS_CHECK_LAUNCH("colsum_reduce_kernel");
+    }
+    return YFS_OK;
+}
+
+// =============================== helpers ========================================================
+namespace {
+
+__global__ void __launch_bounds__(kThreads) leaky_bwd_kernel(const bf16x8* __restrict__ dy, const bf16x8* __restrict__ y,
+                                                             bf16x8* __restrict__ dz, long long n8, float slope) {
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n8; i += (long long)gridDim.x * kThreads) {
+        const bf16x8 a = dy[i], b = y[i];
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (float)b[j] > 0.0f ? a[j] : (bf16_t)((float)a[j] * slope);
+        dz[i] = o;
+    }
+}
+
+// fp32 [Cout][T][Cin] -> bf16 same layout (w16) and bf16 [Cin][T][Cout] with taps reversed (wt16).
+// 64 x 64 (co x ci) tile per block for one tap, transposed through LDS.
+__global__ void __launch_bounds__(kThreads) weight_prep_kernel(const float* __restrict__ w, bf16_t* __restrict__ w16,
+                                                               bf16_t* __restrict__ wt16, int Cout, int T, int Cin) {
+    __shared__ float tile[64][64 + 1];
+    const int tap = blockIdx.z, co0 = blockIdx.y * 64, ci0 = blockIdx.x * 64;
+    const int c = threadIdx.x & 63, r4 = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r4 + 4 * i;
+        const long long o = ((long long)(co0 + r) * T + tap) * Cin + ci0 + c;
+        const float v = w[o];
+        tile[r][c] = v;
+        if (w16) w16[o] = (bf16_t)v;
+    }
+    __syncthreads();
+    if (wt16) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = r4 + 4 * i;   // ci
+            wt16[((long long)(ci0 + r) * T + (T - 1 - tap)) * Cout + co0 + c] = (bf16_t)tile[c][r];
+        }
+    }
+}
+
+// im2col for the Cin=3 stem: one thread per (pixel, 8-wide K chunk).
+template <typename TIn>
+__global__ void __launch_bounds__(kThreads) im2col_kernel(const TIn* __restrict__ x, bf16_t* __restrict__ cols, int H, int W,
+                                                          int Cin, int K, int stride, int pad, int OH, int OW, int Kpad,
+                                                          long long total_chunks) {
+    const int cpr = Kpad / 8;
+    for (long long id = (long long)blockIdx.x * kThreads + threadIdx.x; id < total_chunks;
+         id += (long long)gridDim.x * kThreads) {
+        const long long m = id / cpr;
+        const int kc = (int)(id - m * cpr) * 8;
+        const int n = (int)(m / ((long long)OH * OW));
+        const int rem = (int)(m - (long long)n * OH * OW);
+        const int oh = rem / OW, ow = rem - oh * OW;
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = kc + j;
+            float v = 0.f;
+            if (k < K * K * Cin) {
+                const int tap = k / Cin, ci = k - tap * Cin;
+                const int ih = oh * stride - pad + tap / K, iw = ow * stride - pad + tap % K;
+                if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+                    v = (float)x[(((long long)n * H + ih) * W + iw) * Cin + ci];
+            }
+            o[j] = (bf16_t)v;
+        }
+        *reinterpret_cast<bf16x8*>(cols + m * Kpad + kc) = o;
+    }
+}
+
+}  // namespace
+
+YFS_API int yfs_leaky_bwd_bf16(const void* dy, const void* y, void* dz, int64_t n, float slope, void* stream) {
+    YFS_REQUIRE(dy && y && dz && n > 0, YFS_ERR_INVALID_ARG, "yfs_leaky_bwd_bf16: null pointer or n <= 0");
+    YFS_REQUIRE(n % 8 == 0, YFS_ERR_UNSUPPORTED, "yfs_leaky_bwd_bf16: n=%lld must be a multiple of 8", (long long)n);
+    long long blk = yfs_cdiv(n / 8, kThreads);
+    if (blk > 4096) blk = 4096;
+    leaky_bwd_kernel<<<dim3((unsigned)blk), dim3(kThreads), 0, (hipStream_t)stream>>>((const bf16x8*)dy, (const bf16x8*)y,
+                                                                                   (bf16x8*)dz, n / 8, slope);
+    YFS_CHECK_LAUNCH("leaky_bwd_kernel");
+    return YFS_OK;
+}
+
+YFS_API int yfs_weight_prep_bf16(const float* w, void* w_bf16, void* wt_bf16, int Cout, int K, int Cin, void* stream) {
+    YFS_REQUIRE(w && (w_bf16 || wt_bf16), YFS_ERR_INVALID_ARG, "yfs_weight_prep_bf16: null pointer");
+    YFS_REQUIRE(Cout > 0 && Cin > 0 && K > 0 && Cout % 64 == 0 && Cin % 64 == 0, YFS_ERR_UNSUPPORTED,
+                "yfs_weight_prep_bf16: Cout=%d, Cin=%d must be positive multiples of 64", Cout, Cin);
+    weight_prep_kernel<<<dim3((unsigned)(Cin / 64), (unsigned)(Cout / 64), (unsigned)(K * K)), dim3(kThreads), 0,
+                         (hipStream_t)stream>>>(w, (bf16_t*)w_bf16, (bf16_t*)wt_bf16, Cout, K * K, Cin);
+    YFS_CHECK_LAUNCH("weight_prep_kernel");
+    return YFS_OK;
+}
+
+YFS_API int yfs_im2col_bf16(const void* x, int x_is_f32, void* cols, int64_t N, int H, int W, int Cin, int K, int stride,
+                            int Kpad, void* stream) {
+    YFS_REQUIRE(x && cols, YFS_ERR_INVALID_ARG, "yfs_im2col_bf16: null pointer");
+    YFS_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && K > 0 && stride > 0, YFS_ERR_INVALID_ARG, "yfs_im2col_bf16: bad shape");
+    YFS_REQUIRE(Kpad % 8 == 0 && Kpad >= K * K * Cin, YFS_ERR_INVALID_ARG,
+                "yfs_im2col_bf16: Kpad=%d must be a multiple of 8 and >= K*K*Cin=%d", Kpad, K * K * Cin);
+    const int pad = K / 2;
+    const int OH = (H + 2 * pad - K) / stride + 1, OW = (W + 2 * pad - K) / stride + 1;
+    const long long total = (long long)N * OH * OW * (Kpad / 8);
+    long long blk = yfs_cdiv(total, kThreads);
+    if (blk > 65536) blk = 65536;
+    hipStream_t s = (hipStream_t)stream;
+    if (x_is_f32)
+        im2col_kernel<float><<<dim3((unsigned)blk), dim3(kThreads), 0, s>>>((const float*)x, (bf16_t*)cols, H, W, Cin, K, stride,
+                                                                        pad, OH, OW, Kpad, total);
+    else
+        im2col_kernel<bf16_t><<<dim3((unsigned)blk), dim3(kThreads), 0, s>>>((const bf16_t*)x, (bf16_t*)cols, H, W, Cin, K,
+                                                                         stride, pad, OH, OW, Kpad, total);
+    YFS_CHECK_LAUNCH("im2col_kernel");
+    return YFS_OK;
+}
