@@ -140,10 +140,13 @@ int yfs_maxpool2_fwd_bf16(const void *x, void *y, int64_t N, int H, int W, int C
 int yfs_maxpool2_bwd_bf16(const void *x, const void *dy, void *dx, int64_t N, int H, int W, int C,
                           int fuse_leaky, float slope, void *stream);
 
-/* clip_grad_norm_ + SGD(momentum, weight_decay)  yolo_toy_regressor_torch.py:333, :378-381, one pass.
- * sumsq: device scalar with the squared global grad norm (yfs_sumsq_f32 accumulates it);
- * p -= lr * (buf = momentum*buf + clip*g + wd*p). first_step != 0 initialises buf = g'. */
-int yfs_sumsq_f32(const float *g, int64_t n, float *sumsq_accum, void *stream);
+/* clip_grad_norm_ + SGD(momentum, weight_decay)  yolo_toy_regressor_torch.py:331-335, :378-381 on flat
+ * fp32 arenas (all parameters / gradients / momentum buffers live in one allocation each).
+ * yfs_sumsq_f32: sumsq_out[0] = sum g^2 (deterministic two-stage reduction).
+ * yfs_sgd_step_f32: clip = min(1, max_norm / (sqrt(*sumsq) + 1e-6)) (no clipping when sumsq == NULL or
+ * max_norm <= 0); d = clip*g + wd*p; buf = first_step ? d : momentum*buf + d; p -= lr*buf. */
+size_t yfs_sumsq_workspace_bytes(int64_t n);
+int yfs_sumsq_f32(const float *g, int64_t n, float *sumsq_out, void *workspace, size_t workspace_bytes, void *stream);
 int yfs_sgd_step_f32(float *p, const float *g, float *buf, int64_t n, const float *sumsq, float max_norm,
                      float lr, float momentum, float weight_decay, int first_step, void *stream);
 

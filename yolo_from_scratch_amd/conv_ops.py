@@ -88,14 +88,16 @@ def conv_dgrad(dz, wt16, in_hw, stride=1, x_act=None, slope=0.1):
     return dx
 
 
-def conv_wgrad(x, dz, k, stride=1, dw=None, db=None, want_db=True):
-    """dw fp32 (logical [Cout,Cin,K,K] channels_last), db fp32 [Cout].  Accumulates when dw/db are given."""
+def conv_wgrad(x, dz, k, stride=1, dw=None, db=None, want_db=True, accumulate=None):
+    """dw fp32 (logical [Cout,Cin,K,K] channels_last), db fp32 [Cout].  When dw/db are given the result is
+    written into them: added when ``accumulate`` (default for given buffers), else overwritten."""
     L.require_cuda(x, dz, dw, db)
     x = nhwc(x, torch.bfloat16)
     dz = nhwc(dz, torch.bfloat16)
     n, cin, h, w = x.shape
     cout = dz.shape[1]
-    accumulate = dw is not None
+    if accumulate is None:
+        accumulate = dw is not None
     if dw is None:
         dw = _empty_nhwc(cout, cin, k, k, x.device, torch.float32)
         db = torch.empty(cout, device=x.device, dtype=torch.float32) if want_db else None

@@ -1,0 +1,360 @@
+"""Drop-in model surface of the reference on the MI355X kernels.
+
+Mirrors yolo_toy_regressor_torch.py: ``Conv2D(in_ch, out_ch, k, s=1)`` (:206-211) and
+``YoloRegressorModel`` (:213-269) with the same attribute names (``feat``, ``fc``), the same module
+indices and therefore the same state-dict keys (``feat.<i>.0.weight/bias``, ``fc.1.*``, ``fc.4.*``), so a
+``best_val_iou.pt`` written by the reference loads here and vice versa.
+
+What differs underneath: activations are bf16 NHWC, every Conv2D block runs as one fused MFMA
+implicit-GEMM launch (conv + bias + LeakyReLU), and when ``feat`` is called as a whole the backward
+pass runs as one chain in which each dgrad applies the previous block's LeakyReLU derivative in its
+epilogue and each pool backward does the same for the block feeding it.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib as L
+from . import conv_ops as co
+
+SLOPE = 0.1
+STEM_KPAD = 192   # 7*7*3 = 147 im2col columns padded to a multiple of 64
+
+
+def _pool_fwd(x):
+    x = co.nhwc(x, torch.bfloat16)
+    n, c, h, w = x.shape
+    y = torch.empty((n, c, h // 2, w // 2), device=x.device, dtype=torch.bfloat16, memory_format=co.CL)
+    L.check(L.lib().yfs_maxpool2_fwd_bf16(L.ptr(x), L.ptr(y), L.i64(n), L.c_int(h), L.c_int(w), L.c_int(c), L.stream()),
+            "yfs_maxpool2_fwd_bf16")
+    return y
+
+
+def _pool_bwd(x, dy, fuse_leaky, slope=SLOPE):
+    x = co.nhwc(x, torch.bfloat16)
+    dy = co.nhwc(dy, torch.bfloat16)
+    n, c, h, w = x.shape
+    dx = torch.empty_like(x)
+    L.check(L.lib().yfs_maxpool2_bwd_bf16(L.ptr(x), L.ptr(dy), L.ptr(dx), L.i64(n), L.c_int(h), L.c_int(w), L.c_int(c),
+                                          L.c_int(1 if fuse_leaky else 0), L.c_float(slope), L.stream()),
+            "yfs_maxpool2_bwd_bf16")
+    return dx
+
+
+def _stem_weight(weight):
+    """[Cout,Cin,K,K] (channels_last fp32) -> [Cout, STEM_KPAD, 1, 1] zero-padded im2col weight."""
+    cout, cin, k, _ = weight.shape
+    wk = torch.zeros((cout, STEM_KPAD, 1, 1), device=weight.device, dtype=torch.float32).contiguous(memory_format=co.CL)
+    wk.view(cout, STEM_KPAD)[:, :cin * k * k] = weight.permute(0, 2, 3, 1).reshape(cout, cin * k * k)
+    return wk
+
+
+class _ConvPlan:
+    """What one Conv2D block needs in forward and backward; shared by the per-layer and the chained path."""
+
+    def __init__(self, weight, bias, stride, need_wt):
+        cout, cin, k, _ = weight.shape
+        self.k, self.stride, self.cin, self.cout = k, stride, cin, cout
+        self.stem = cin % 64 != 0
+        if self.stem:
+            self.w16, _ = co.weight_prep(_stem_weight(weight), want_wt16=False)
+            self.wt16 = None
+        else:
+            self.w16, self.wt16 = co.weight_prep(weight, want_wt16=need_wt)
+        self.bias = bias.detach().float().contiguous()
+
+    def forward(self, x):
+        """x: NHWC bf16 (or fp32/bf16 image for the stem). Returns (gemm_input, y)."""
+        if self.stem:
+            cols = co.im2col(x, self.k, self.stride, STEM_KPAD)
+            return cols, co.conv_fwd(cols, self.w16, self.bias, 1, SLOPE)
+        x = co.nhwc(x, torch.bfloat16)
+        return x, co.conv_fwd(x, self.w16, self.bias, self.stride, SLOPE)
+
+    def wgrad(self, gemm_in, dz, weight, bias):
+        """Weight / bias gradients: written into the parameters' gradient sinks when they have one (returns
+        None then), else returned (dw in the weight's logical shape, channels_last fp32)."""
+        from .train import write_grad
+        wsink = getattr(weight, "_yfs_grad_sink", None)
+        bsink = getattr(bias, "_yfs_grad_sink", None)
+        if self.stem:
+            dwk, db = co.conv_wgrad(gemm_in, dz, 1, 1)
+            cout, cin, k, _ = weight.shape
+            dwv = dwk.view(cout, STEM_KPAD)[:, :cin * k * k]
+
+            def put_w(sink, acc):
+                if sink is None:
+                    return dwv.reshape(cout, k, k, cin).permute(0, 3, 1, 2)
+                flat = sink.permute(0, 2, 3, 1).reshape(cout, cin * k * k)   # a view: sink is channels_last
+                flat.add_(dwv) if acc else flat.copy_(dwv)
+
+            def put_b(sink, acc):
+                if sink is None:
+                    return db
+                sink.add_(db) if acc else sink.copy_(db)
+            return write_grad(weight, put_w), write_grad(bias, put_b)
+        if wsink is not None and bsink is not None:
+            acc = not weight._yfs_grad_fresh
+            co.conv_wgrad(gemm_in, dz, self.k, self.stride, dw=wsink, db=bsink, accumulate=acc)
+            weight._yfs_grad_fresh = bias._yfs_grad_fresh = False
+            return None, None
+        return co.conv_wgrad(gemm_in, dz, self.k, self.stride)
+
+
+class _ConvBlockFn(torch.autograd.Function):
+    """One Conv2D block on its own (used when a block is called outside a Backbone chain)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride):
+        L.require_cuda(x, weight, bias)
+        plan = _ConvPlan(weight, bias, stride, need_wt=ctx.needs_input_grad[0])
+        gin, y = plan.forward(x)
+        ctx.plan, ctx.in_shape, ctx.in_dtype = plan, x.shape, x.dtype
+        ctx.wb = (weight, bias)
+        ctx.save_for_backward(gin, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        gin, y = ctx.saved_tensors
+        plan = ctx.plan
+        dz = co.leaky_bwd(dy, y, SLOPE)
+        dw, db = plan.wgrad(gin, dz, *ctx.wb)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if plan.stem:
+                raise L.YfsError("input gradient of the Cin=3 stem is not implemented (the reference never needs it)")
+            dx = co.conv_dgrad(dz, plan.wt16, ctx.in_shape[2:], plan.stride).to(ctx.in_dtype)
+        return dx, dw, db, None
+
+
+class HipConv2d(nn.Module):
+    """nn.Conv2d(in_ch, out_ch, k, stride=s, padding=k//2) whose forward also applies LeakyReLU(0.1).
+    Parameters keep nn.Conv2d's names, shapes and default init; the weight is stored channels_last."""
+
+    def __init__(self, in_ch, out_ch, k, stride=1):
+        super().__init__()
+        ref = nn.Conv2d(in_ch, out_ch, k, stride=stride, padding=k // 2)    # default init, same RNG consumption
+        self.weight = nn.Parameter(ref.weight.detach().contiguous(memory_format=co.CL))
+        self.bias = nn.Parameter(ref.bias.detach())
+        self.weight._yfs_sink_capable = self.bias._yfs_sink_capable = True
+        self.in_channels, self.out_channels, self.kernel_size, self.stride = in_ch, out_ch, k, stride
+
+    def forward(self, x):
+        return _ConvBlockFn.apply(x, self.weight, self.bias, self.stride)
+
+    def extra_repr(self):
+        return f"{self.in_channels}, {self.out_channels}, k={self.kernel_size}, s={self.stride}, fused LeakyReLU({SLOPE})"
+
+
+class FusedLeakyReLU(nn.Module):
+    """Placeholder at index 1 of a Conv2D block: the activation already ran in the conv epilogue."""
+
+    def __init__(self, negative_slope=SLOPE):
+        super().__init__()
+        self.negative_slope = negative_slope
+
+    def forward(self, x):
+        return x
+
+
+def Conv2D(in_ch, out_ch, k, s=1):
+    """Reference signature (yolo_toy_regressor_torch.py:206): Sequential(conv, LeakyReLU(0.1))."""
+    return nn.Sequential(HipConv2d(in_ch, out_ch, k, s), FusedLeakyReLU(SLOPE))
+
+
+class _PoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        L.require_cuda(x)
+        x16 = co.nhwc(x, torch.bfloat16)
+        ctx.save_for_backward(x16)
+        ctx.in_dtype = x.dtype
+        return _pool_fwd(x16)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x16,) = ctx.saved_tensors
+        return _pool_bwd(x16, dy, fuse_leaky=False).to(ctx.in_dtype)
+
+
+class HipMaxPool2d(nn.Module):
+    """nn.MaxPool2d(kernel_size=2, stride=2) on NHWC bf16."""
+
+    def forward(self, x):
+        return _PoolFn.apply(x)
+
+
+class _BackboneFn(torch.autograd.Function):
+    """All of ``feat`` as one autograd node: forward = chain of fused conv / pool launches; backward walks
+    it in reverse with the LeakyReLU derivative folded into dgrad epilogues and pool backward."""
+
+    @staticmethod
+    def forward(ctx, x, stages, *params):
+        L.require_cuda(x)
+        plans, acts, gins = [], [], []
+        h = x
+        pi = 0
+        for st in stages:
+            if st == "P":
+                h = _pool_fwd(h)
+                plans.append(None)
+                gins.append(None)
+            else:
+                w, b = params[pi], params[pi + 1]
+                pi += 2
+                plan = _ConvPlan(w, b, st, need_wt=len(plans) > 0)
+                gin, h = plan.forward(h)
+                plans.append(plan)
+                gins.append(gin)
+            acts.append(h)
+        ctx.stages, ctx.plans = stages, plans
+        ctx.params = params
+        ctx.acts, ctx.gins = acts, gins   # kept on ctx: bf16 activations are internal, never user-visible
+        return h
+
+    @staticmethod
+    def backward(ctx, dy):
+        stages, plans, acts, gins = ctx.stages, ctx.plans, ctx.acts, ctx.gins
+        grads = [None] * len(ctx.params)
+        nconv = sum(1 for s in stages if s != "P")
+        pi = 2 * nconv
+        last = len(stages) - 1
+        g = co.nhwc(dy, torch.bfloat16)
+        if stages[last] != "P":
+            g = co.leaky_bwd(g, acts[last], SLOPE)
+        for i in range(last, -1, -1):
+            if stages[i] == "P":
+                g = _pool_bwd(acts[i - 1], g, fuse_leaky=(i > 0 and stages[i - 1] != "P"))
+                continue
+            plan = plans[i]
+            pi -= 2
+            dw, db = plan.wgrad(gins[i], g, ctx.params[pi], ctx.params[pi + 1])
+            grads[pi], grads[pi + 1] = dw, db
+            if i == 0:
+                break
+            prev_is_conv = stages[i - 1] != "P"
+            g = co.conv_dgrad(g, plan.wt16, acts[i - 1].shape[2:], plan.stride,
+                              x_act=acts[i - 1] if prev_is_conv else None, slope=SLOPE)
+        ctx.acts = ctx.gins = ctx.plans = ctx.params = None
+        return (None, None) + tuple(grads)
+
+
+class Backbone(nn.Sequential):
+    """nn.Sequential whose whole-chain call is one fused autograd node when every child is a Conv2D
+    block or a 2x2 max pool (true for ``feat``); otherwise it behaves like nn.Sequential."""
+
+    def _chainable(self):
+        for m in self:
+            ok = isinstance(m, HipMaxPool2d) or (isinstance(m, nn.Sequential) and len(m) == 2 and
+                                                 isinstance(m[0], HipConv2d) and isinstance(m[1], FusedLeakyReLU))
+            if not ok:
+                return False
+        return len(self) > 0 and not isinstance(self[0], HipMaxPool2d)
+
+    def forward(self, x):
+        if not (x.is_cuda and self._chainable()):
+            return super().forward(x)
+        stages, params = [], []
+        for m in self:
+            if isinstance(m, HipMaxPool2d):
+                stages.append("P")
+            else:
+                stages.append(m[0].stride)
+                params += [m[0].weight, m[0].bias]
+        return _BackboneFn.apply(x, tuple(stages), *params)
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b in bf16 on hipBLASLt (through PyTorch-ROCm: a plain library GEMM, not one of the four
+    hand-written kernel sets), fp32 master weight, gradients written into the optimiser's arena."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x16 = x.to(torch.bfloat16)
+        w16 = weight.detach().to(torch.bfloat16)
+        ctx.save_for_backward(x16, w16)
+        ctx.wb, ctx.in_dtype = (weight, bias), x.dtype
+        return torch.addmm(bias.detach().to(torch.bfloat16), x16, w16.t())
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .train import write_grad
+        x16, w16 = ctx.saved_tensors
+        weight, bias = ctx.wb
+        dy16 = dy.to(torch.bfloat16).contiguous()
+        dx = torch.mm(dy16, w16).to(ctx.in_dtype) if ctx.needs_input_grad[0] else None
+        dw16 = torch.mm(dy16.t(), x16)
+
+        def put_w(sink, acc):
+            if sink is None:
+                return dw16.float()
+            sink.add_(dw16) if acc else sink.copy_(dw16)
+
+        def put_b(sink, acc):
+            db = dy16.float().sum(0)
+            if sink is None:
+                return db
+            sink.add_(db) if acc else sink.copy_(db)
+        dw, db = write_grad(weight, put_w), write_grad(bias, put_b)
+        ctx.wb = None
+        return dx, dw, db
+
+
+class HipLinear(nn.Linear):
+    """nn.Linear with the same parameter names/init; bf16 compute, fp32 master weights."""
+
+    def __init__(self, in_features, out_features):
+        super().__init__(in_features, out_features)
+        self.weight._yfs_sink_capable = self.bias._yfs_sink_capable = True
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise L.YfsError("HipLinear runs on the MI355X only")
+        return _LinearFn.apply(x, self.weight, self.bias)
+
+
+class YoloRegressorModel(nn.Module):
+    """Reference YoloRegressorModel (yolo_toy_regressor_torch.py:213-269).
+
+    ``head_out`` = 4 reproduces the reference ([xc,yc,w,h]); 7*7*30 = 1470 gives the YOLOv1 S=7,B=2,C=20
+    head that BASELINE.json's train-step config uses (build-defined: the reference stops at 4 outputs).
+    ``image_size`` sizes fc.1 the way the reference's 448 dummy forward does (:255-257).
+    """
+
+    def __init__(self, head_out=4, image_size=448, p_drop=0.2):
+        super().__init__()
+        pool = HipMaxPool2d
+        self.feat = Backbone(
+            Conv2D(3, 192, 7, s=2), pool(),
+            Conv2D(192, 256, 3), pool(),
+            Conv2D(256, 128, 1), Conv2D(128, 256, 3), Conv2D(256, 256, 1), Conv2D(256, 512, 3), pool(),
+            Conv2D(512, 256, 1), Conv2D(256, 512, 3), Conv2D(512, 256, 1), Conv2D(256, 512, 3),
+            Conv2D(512, 256, 1), Conv2D(256, 512, 3), Conv2D(512, 256, 1), Conv2D(256, 512, 3),
+            Conv2D(512, 512, 1), Conv2D(512, 1024, 3), pool(),
+            Conv2D(1024, 512, 1), Conv2D(512, 1024, 3), Conv2D(1024, 512, 1), Conv2D(512, 1024, 3),
+            Conv2D(1024, 1024, 3),
+            Conv2D(1024, 1024, 3, s=2),
+            Conv2D(1024, 1024, 3), Conv2D(1024, 1024, 3),
+        )
+        hw = image_size
+        for m in self.feat:
+            hw = hw // 2 if isinstance(m, HipMaxPool2d) else co.out_hw(hw, hw, m[0].kernel_size, m[0].stride)[0]
+        flat = 1024 * hw * hw
+        self.fc = nn.Sequential(
+            nn.Flatten(),
+            HipLinear(flat, 4096),
+            nn.LeakyReLU(0.1, inplace=True),
+            nn.Dropout(p_drop),
+            HipLinear(4096, head_out),
+        )
+
+    def forward(self, x):
+        x = self.feat(x)
+        # the reference flattens NCHW; x is NHWC in memory, so flatten() permutes (6 MB at batch 64)
+        return self.fc(x).float()
+
+
+def load_reference_state_dict(model, state_dict):
+    """Load a checkpoint written by the reference (contiguous NCHW weights); layouts are converted by copy_."""
+    return model.load_state_dict(state_dict)

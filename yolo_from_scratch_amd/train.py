@@ -1,0 +1,196 @@
+"""Step driver — the reference's train/eval surface (yolo_toy_regressor_torch.py:272-339) plus the
+MI355X-native optimiser: all parameters, gradients and momentum buffers live in three flat fp32 arenas
+(1.06 GB each for the 266 M-parameter model; HBM is 288 GB), backward writes weight gradients straight
+into the gradient arena, and clip_grad_norm_ + SGD run as two HBM-bound launches over the arenas.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .boxes import iou_xywh_torch
+
+
+# ---- yolo_toy_regressor_torch.py:272-280 --------------------------------------------------------
+def yolo_v1_lr_schedule(epoch, total_epochs=135, warmup=5):
+    if epoch < warmup:
+        return 1e-3 + (1e-2 - 1e-3) * (epoch + 1) / max(1, warmup)
+    elif epoch < warmup + 75:
+        return 1e-2
+    elif epoch < warmup + 75 + 30:
+        return 1e-3
+    else:
+        return 1e-4
+
+
+# ---- yolo_toy_regressor_torch.py:282-296 --------------------------------------------------------
+class EarlyStoppingMax:
+    def __init__(self, patience=12, min_delta=0.0):
+        self.best = -float("inf")
+        self.patience = patience
+        self.min_delta = min_delta
+        self.count = 0
+
+    def step(self, metric):
+        improved = metric > self.best + self.min_delta
+        if improved:
+            self.best = metric
+            self.count = 0
+        else:
+            self.count += 1
+        return improved, self.count >= self.patience
+
+
+class FlatSGD(torch.optim.Optimizer):
+    """SGD(momentum, weight_decay) with fused clip_grad_norm_ over flat arenas.
+
+    Construction re-homes every parameter into one flat fp32 buffer (values preserved, layouts
+    preserved) and gives each a persistent ``.grad`` view into a flat gradient buffer.  The conv and
+    linear autograd nodes of this package write gradients directly into those views (``_yfs_grad_sink``);
+    anything else reaches them through autograd's normal in-place accumulation.
+    ``comm`` (optional) is a gradient-exchange object with ``reduce(flat_grads)`` (see dp.py).
+    """
+
+    def __init__(self, params, lr=1e-3, momentum=0.9, weight_decay=5e-4, max_norm=None, comm=None):
+        params = list(params)
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+        if not params or not all(p.is_cuda for p in params):
+            raise L.YfsError("FlatSGD needs CUDA (MI355X) parameters")
+        dev = params[0].device
+        sizes = [(p.numel() + 63) // 64 * 64 for p in params]          # 256-byte aligned slices
+        total = sum(sizes)
+        self.flat_p = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.flat_g = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.flat_m = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.offsets = []
+        off = 0
+        for p, sz in zip(params, sizes):
+            n = p.numel()
+            if not (p.is_contiguous() or p.is_contiguous(memory_format=torch.channels_last)):
+                raise L.YfsError("FlatSGD: parameters must be dense")
+            pv = torch.as_strided(self.flat_p, p.shape, p.stride(), off)
+            pv.copy_(p.data)
+            p.data = pv
+            gv = torch.as_strided(self.flat_g, p.shape, p.stride(), off)
+            p.grad = gv
+            p._yfs_grad_sink = gv
+            p._yfs_grad_fresh = bool(getattr(p, "_yfs_sink_capable", False))
+            self.offsets.append((off, n))
+            off += sz
+        self.total = total
+        self.max_norm = max_norm
+        self.comm = comm
+        self._first = True
+        self._sumsq = torch.zeros(1, device=dev, dtype=torch.float32)
+        ws_bytes = L.lib().yfs_sumsq_workspace_bytes(L.i64(total))
+        self._ws = torch.empty(ws_bytes // 4 + 1, device=dev, dtype=torch.float32)
+        self._ws_bytes = ws_bytes
+
+    def zero_grad(self, set_to_none=True):
+        """Gradients stay allocated (they are arena views).  Parameters owned by this package's layers are
+        marked fresh: their next backward overwrites the view instead of adding.  Any other parameter
+        receives its gradient through autograd's in-place accumulation, so its view is cleared here."""
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is not p._yfs_grad_sink:
+                    p.grad = p._yfs_grad_sink
+                if getattr(p, "_yfs_sink_capable", False):
+                    p._yfs_grad_fresh = True
+                else:
+                    p._yfs_grad_sink.zero_()
+                    p._yfs_grad_fresh = False
+
+    def _finish_grads(self):
+        """A sink-capable parameter that took no part in this step's backward still holds last step's
+        gradient: clear it (autograd would have left .grad = None)."""
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p._yfs_grad_fresh:
+                    p._yfs_grad_sink.zero_()
+                    p._yfs_grad_fresh = False
+
+    @torch.no_grad()
+    def grad_norm(self):
+        L.check(L.lib().yfs_sumsq_f32(L.ptr(self.flat_g), L.i64(self.total), L.ptr(self._sumsq), L.ptr(self._ws),
+                                      L.c_size(self._ws_bytes), L.stream()), "yfs_sumsq_f32")
+        return self._sumsq
+
+    @torch.no_grad()
+    def step(self, closure=None, max_norm="default"):
+        if max_norm == "default":
+            max_norm = self.max_norm
+        self._finish_grads()
+        if self.comm is not None:
+            self.comm.reduce(self.flat_g)
+        g = self.param_groups[0]
+        sumsq = None
+        if max_norm is not None and max_norm > 0:
+            sumsq = self.grad_norm()
+        L.check(L.lib().yfs_sgd_step_f32(L.ptr(self.flat_p), L.ptr(self.flat_g), L.ptr(self.flat_m), L.i64(self.total),
+                                         L.ptr(sumsq), L.c_float(max_norm or 0.0), L.c_float(g["lr"]),
+                                         L.c_float(g["momentum"]), L.c_float(g["weight_decay"]),
+                                         L.c_int(1 if self._first else 0), L.stream()), "yfs_sgd_step_f32")
+        self._first = False
+
+
+def write_grad(param, value_fn):
+    """Used by this package's autograd nodes: if ``param`` has a gradient sink, let ``value_fn(sink, accumulate)``
+    write into it and return None (autograd then has nothing to accumulate); otherwise return the gradient."""
+    sink = getattr(param, "_yfs_grad_sink", None)
+    if sink is None:
+        return value_fn(None, False)
+    value_fn(sink, not param._yfs_grad_fresh)
+    param._yfs_grad_fresh = False
+    return None
+
+
+# ---- yolo_toy_regressor_torch.py:298-312 --------------------------------------------------------
+@torch.no_grad()
+def evaluate(model, loader, device, loss_fn):
+    model.eval()
+    total_loss = 0.0
+    total_iou = 0.0
+    n = 0
+    for xb, yb in loader:
+        xb = xb.to(device, non_blocking=True)
+        yb = yb.to(device, non_blocking=True)
+        preds = model(xb)
+        loss = loss_fn(preds, yb)
+        total_loss += loss.item() * xb.size(0)
+        if preds.dim() == 2 and preds.shape[1] == 4:
+            total_iou += iou_xywh_torch(preds, yb) * xb.size(0)
+        n += xb.size(0)
+    return total_loss / n, total_iou / n
+
+
+# ---- yolo_toy_regressor_torch.py:314-339 --------------------------------------------------------
+def train_one_epoch(model, loader, device, opt, scaler, loss_fn, max_norm=1.0):
+    """Same call and return as the reference.  The model computes in bf16 internally, so ``scaler`` may be a
+    disabled GradScaler (or None); an enabled one still works (bf16 has fp32's exponent range)."""
+    model.train()
+    running = 0.0
+    n = 0
+    flat = isinstance(opt, FlatSGD)
+    for xb, yb in loader:
+        xb = xb.to(device, non_blocking=True)
+        yb = yb.to(device, non_blocking=True)
+        opt.zero_grad(set_to_none=True)
+        preds = model(xb)
+        loss = loss_fn(preds, yb)
+        if scaler is not None and scaler.is_enabled():
+            scaler.scale(loss).backward()
+            scaler.unscale_(opt)
+            if max_norm is not None:
+                nn.utils.clip_grad_norm_(model.parameters(), max_norm)
+            scaler.step(opt, max_norm=None) if flat else scaler.step(opt)
+            scaler.update()
+        else:
+            loss.backward()
+            if flat:
+                opt.step(max_norm=max_norm)
+            else:
+                if max_norm is not None:
+                    nn.utils.clip_grad_norm_(model.parameters(), max_norm)
+                opt.step()
+        running += loss.item() * xb.size(0)
+        n += xb.size(0)
+    return running / n
