@@ -1,0 +1,118 @@
+"""Data-parallel gradient exchange: one process per GPU, torch.distributed over RCCL/xGMI.
+
+The reference is single-device (yolo_toy_regressor_torch.py:375); this is new work.
+Design for the MI355X node:
+  * gradients already live in ONE flat fp32 arena (train.FlatSGD), so buckets are plain slices of it —
+    no gather/scatter copies;
+  * buckets are cut in REVERSE parameter order: backward produces fc.4, fc.1 first and fc.1 alone is 77 %
+    of the payload, so the biggest transfer starts first and hides under the whole conv backward;
+  * each bucket's all-reduce is issued on a side stream as soon as every parameter in it has reported its
+    gradient (``notify``), ordered after the producing kernels by an event; ``finish`` makes the compute
+    stream wait for all of them before clip_grad_norm_/SGD read the arena (the reference clips AFTER
+    backward, :331-333, so the reduced gradient is what must be clipped);
+  * xGMI is point-to-point (7 links per GPU): a few large messages, not many small ones — the bucket
+    size is 256 MB by default, so the 1.06 GB payload travels as ~5 collectives.
+Averaging: SUM all-reduce, then the 1/world factor is folded into the bf16->fp32 copy-back (compressed
+mode) or applied as one in-place scale on the side stream (fp32 mode).
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradComm:
+    def __init__(self, world_size=None, bucket_bytes=256 << 20, compress_bf16=False, group=None):
+        self.group = group
+        self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.bucket_bytes = bucket_bytes
+        self.compress = compress_bf16
+        self.buckets = []          # (start, end) element ranges of the flat arena, in issue order
+        self.param_bucket = {}     # id(param) -> bucket index
+        self.pending = []          # params not yet reported, per bucket
+        self.flat = None
+        self.stream = None
+        self._issued = []
+        self._c16 = None
+
+    # -- layout -----------------------------------------------------------------------------------
+    def attach(self, params, offsets, flat_g):
+        """params / offsets as laid out by FlatSGD (registration order); buckets are cut from the END."""
+        self.flat = flat_g
+        per = max(1, self.bucket_bytes // 4)
+        self.buckets, self.param_bucket = [], {}
+        cur_hi, cur_lo, members = None, None, []
+        for p, (off, n) in zip(reversed(params), reversed(offsets)):
+            if cur_hi is None:
+                cur_hi = off + n
+            cur_lo = off
+            members.append(p)
+            if cur_hi - cur_lo >= per:
+                self._close(cur_lo, cur_hi, members)
+                cur_hi, members = None, []
+        if members:
+            self._close(cur_lo, cur_hi, members)
+        if flat_g.is_cuda:
+            self.stream = torch.cuda.Stream(device=flat_g.device)
+            if self.compress:
+                self._c16 = torch.empty(max(e - s for s, e in self.buckets), device=flat_g.device, dtype=torch.bfloat16)
+        self.begin_step()
+
+    def _close(self, lo, hi, members):
+        idx = len(self.buckets)
+        self.buckets.append((lo, hi))
+        for p in members:
+            self.param_bucket[id(p)] = idx
+
+    # -- per step ------------------------------------------------------------------------------------
+    def begin_step(self):
+        self.pending = [0] * len(self.buckets)
+        for idx in self.param_bucket.values():
+            self.pending[idx] += 1
+        self._issued = [False] * len(self.buckets)
+
+    def notify(self, param):
+        """Called by the autograd nodes right after they enqueue the kernel that writes param's gradient."""
+        if self.world <= 1:
+            return
+        idx = self.param_bucket.get(id(param))
+        if idx is None or self._issued[idx]:
+            return
+        self.pending[idx] -= 1
+        if self.pending[idx] == 0:
+            self._issue(idx)
+
+    def _issue(self, idx):
+        self._issued[idx] = True
+        lo, hi = self.buckets[idx]
+        chunk = self.flat[lo:hi]
+        if self.stream is None:                               # CPU / gloo (tests)
+            dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
+            chunk.mul_(1.0 / self.world)
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ev)
+            if self.compress:
+                c = self._c16[: hi - lo]
+                c.copy_(chunk)
+                dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group)
+                torch.mul(c, 1.0 / self.world, out=chunk)
+            else:
+                dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
+                chunk.mul_(1.0 / self.world)
+
+    def reduce(self, flat_g):
+        """Issue whatever has not been issued yet (parameters that never reported) and wait for everything."""
+        if self.world > 1:
+            for idx in range(len(self.buckets)):
+                if not self._issued[idx]:
+                    self._issue(idx)
+            if self.stream is not None:
+                torch.cuda.current_stream().wait_stream(self.stream)
+        self.begin_step()
+
+
+def broadcast_parameters(flat_p, src=0, group=None):
+    """Identical initial weights on every rank."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(flat_p, src=src, group=group)

@@ -97,6 +97,9 @@ class _ConvPlan:
             acc = not weight._yfs_grad_fresh
             co.conv_wgrad(gemm_in, dz, self.k, self.stride, dw=wsink, db=bsink, accumulate=acc)
             weight._yfs_grad_fresh = bias._yfs_grad_fresh = False
+            from .train import grad_ready
+            grad_ready(weight)
+            grad_ready(bias)
             return None, None
         return co.conv_wgrad(gemm_in, dz, self.k, self.stride)
 

@@ -79,6 +79,11 @@ class FlatSGD(torch.optim.Optimizer):
         self.total = total
         self.max_norm = max_norm
         self.comm = comm
+        self._params = params
+        if comm is not None:
+            comm.attach(params, self.offsets, self.flat_g)
+            for p in params:
+                p._yfs_comm = comm
         self._first = True
         self._sumsq = torch.zeros(1, device=dev, dtype=torch.float32)
         ws_bytes = L.lib().yfs_sumsq_workspace_bytes(L.i64(total))
@@ -107,6 +112,9 @@ class FlatSGD(torch.optim.Optimizer):
                 if p._yfs_grad_fresh:
                     p._yfs_grad_sink.zero_()
                     p._yfs_grad_fresh = False
+                    grad_ready(p)
+                elif not getattr(p, "_yfs_sink_capable", False):
+                    grad_ready(p)       # gradient came through plain autograd: complete by now
 
     @torch.no_grad()
     def grad_norm(self):
@@ -140,7 +148,15 @@ def write_grad(param, value_fn):
         return value_fn(None, False)
     value_fn(sink, not param._yfs_grad_fresh)
     param._yfs_grad_fresh = False
+    grad_ready(param)
     return None
+
+
+def grad_ready(param):
+    """Tell the gradient exchange (if any) that param's gradient kernel has been enqueued."""
+    comm = getattr(param, "_yfs_comm", None)
+    if comm is not None:
+        comm.notify(param)
 
 
 # ---- yolo_toy_regressor_torch.py:298-312 --------------------------------------------------------
