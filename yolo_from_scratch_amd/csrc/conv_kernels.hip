@@ -24,6 +24,18 @@ typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+// Raw buffer descriptor over a whole tensor: loads whose byte offset is >= num_records return zeros in
+// hardware, which is how conv padding, tile tails and strided-dgrad holes are produced without branches
+// (a predicated global_load forces the compiler to wait for it right away; these stay in flight).
+constexpr unsigned kOOB = 0xFFFFFFFFu;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+}
 
 constexpr int kThreads = 256;
 constexpr int BK = 64;   // reduction depth per LDS tile (128 B rows)
@@ -38,6 +50,7 @@ struct IgemmArgs {
     bf16_t* out;          // [M][NOUT]
     int N, H, W, C;
     int OH, OW, NOUT;
+    unsigned xbytes, wbytes;
     int KS;               // taps = KS*KS
     int s_mul, pad, dil;  // src = o*s_mul - pad + k ; dil > 1: src must divide by dil (strided dgrad)
     int M;                // N*OH*OW
@@ -72,9 +85,9 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(IgemmArgs g) {
 
     // ---- per-thread staging coordinates -------------------------------------------------------
     const int chunk = tid & 7, srow = tid >> 3;   // 32 rows per pass
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.x, g.xbytes), rw = make_rsrc(g.w, g.wbytes);
     int bh[RA], bw[RA];
-    long long ximg[RA];
-    int rowoff[RA];
+    unsigned rowbyte[RA];   // byte offset of (n, bh, bw, chunk) — wraps mod 2^32 for negative bh/bw, fixed up by + tap offset
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
         const int m = m0 + srow + 32 * i;
@@ -84,43 +97,44 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(IgemmArgs g) {
             const int oh = rem / g.OW, ow = rem - oh * g.OW;
             bh[i] = oh * g.s_mul - g.pad;
             bw[i] = ow * g.s_mul - g.pad;
-            ximg[i] = (long long)n * g.H * g.W * g.C;
+            if (DIL) rowbyte[i] = (unsigned)n * (unsigned)(g.H * g.W * g.C * 2) + chunk * 16;
+            else rowbyte[i] = (unsigned)(((long long)(n * g.H + bh[i]) * g.W + bw[i]) * g.C * 2) + chunk * 16;
         } else {
             bh[i] = -(1 << 28);
             bw[i] = -(1 << 28);
-            ximg[i] = 0;
+            rowbyte[i] = 0;
         }
-        rowoff[i] = chunk * 8;
     }
-    const long long ktot = (long long)g.KS * g.KS * g.C;
-    const bf16_t* wbase = g.w + (long long)(n0 + srow) * ktot + chunk * 8;
+    const unsigned ktot = (unsigned)(g.KS * g.KS * g.C);
+    const unsigned wrow = (unsigned)(n0 + srow) * ktot * 2 + chunk * 16;
 
     const int cchunks = g.C / BK;
     const int nit = g.KS * g.KS * cchunks;
 
-    bf16x8 ra[RA], rb[RB];
+    u32x4 ra[RA], rb[RB];
     int kh = 0, kw = 0, cc = 0;   // position of the NEXT tile to load
 
     auto load_tile = [&](int it) {
+        const unsigned tapoff = (unsigned)(((kh * g.W + kw) * g.C + cc * BK) * 2);
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             int sh = bh[i] + kh, sw = bw[i] + kw;
+            unsigned off;
             bool ok;
             if (DIL) {
                 ok = sh >= 0 && sw >= 0 && (sh % g.dil) == 0 && (sw % g.dil) == 0;
                 sh /= g.dil;
                 sw /= g.dil;
                 ok = ok && sh < g.H && sw < g.W;
+                off = rowbyte[i] + (unsigned)(((sh * g.W + sw) * g.C + cc * BK) * 2);
             } else {
                 ok = (unsigned)sh < (unsigned)g.H && (unsigned)sw < (unsigned)g.W;
+                off = rowbyte[i] + tapoff;
             }
-            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (ok) v = *reinterpret_cast<const bf16x8*>(g.x + ximg[i] + ((long long)(sh * g.W + sw) * g.C + cc * BK + rowoff[i]));
-            ra[i] = v;
+            ra[i] = buf_load16(rx, ok ? off : kOOB);
         }
 #pragma unroll
-        for (int i = 0; i < RB; ++i)
-            rb[i] = *reinterpret_cast<const bf16x8*>(wbase + (long long)(32 * i) * ktot + (long long)it * BK);
+        for (int i = 0; i < RB; ++i) rb[i] = buf_load16(rw, wrow + (unsigned)(32 * i) * ktot * 2 + (unsigned)it * (BK * 2));
         if (++cc == cchunks) {
             cc = 0;
             if (++kw == g.KS) { kw = 0; ++kh; }
@@ -129,9 +143,9 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(IgemmArgs g) {
     auto store_tile = [&](int buf) {
         unsigned char* base = smem + buf * TILE_BYTES;
 #pragma unroll
-        for (int i = 0; i < RA; ++i) *reinterpret_cast<bf16x8*>(base + swz(srow + 32 * i, chunk)) = ra[i];
+        for (int i = 0; i < RA; ++i) *reinterpret_cast<u32x4*>(base + swz(srow + 32 * i, chunk)) = ra[i];
 #pragma unroll
-        for (int i = 0; i < RB; ++i) *reinterpret_cast<bf16x8*>(base + BM * 128 + swz(srow + 32 * i, chunk)) = rb[i];
+        for (int i = 0; i < RB; ++i) *reinterpret_cast<u32x4*>(base + BM * 128 + swz(srow + 32 * i, chunk)) = rb[i];
     };
 
     f32x4 acc[FC][FP];
@@ -251,8 +265,8 @@ int check_conv_shape(const char* fn, int64_t N, int H, int W, int Cin, int Cout,
     YFS_REQUIRE(Cout % 64 == 0, YFS_ERR_UNSUPPORTED, "%s: Cout=%d must be a multiple of 64", fn, Cout);
     const int pad = K / 2;
     const int64_t Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
-    YFS_REQUIRE(N * Ho * Wo < (1ll << 31) && (int64_t)H * W * Cin < (1ll << 31), YFS_ERR_UNSUPPORTED,
-                "%s: tensor too large for 32-bit pixel indexing", fn);
+    YFS_REQUIRE(N * Ho * Wo * Cout * 2 < 0xFFFFFF00ll && N * H * W * Cin * 2 < 0xFFFFFF00ll, YFS_ERR_UNSUPPORTED,
+                "%s: an activation tensor exceeds the 4 GiB range of one buffer descriptor (split the batch)", fn);
     return YFS_OK;
 }
 
@@ -270,6 +284,7 @@ YFS_API int yfs_conv2d_fwd_bf16(const void* x, const void* w, const float* bias,
     g.OH = (H + 2 * pad - K) / stride + 1; g.OW = (W + 2 * pad - K) / stride + 1; g.NOUT = Cout;
     g.KS = K; g.s_mul = stride; g.pad = pad; g.dil = 1; g.slope = slope;
     g.M = (int)(N * g.OH * g.OW);
+    g.xbytes = (unsigned)(N * H * W * Cin * 2); g.wbytes = (unsigned)((int64_t)Cout * K * K * Cin * 2);
     return dispatch_igemm<EPI_BIAS_LEAKY, false>(g, (hipStream_t)stream, "yfs_conv2d_fwd_bf16");
 }
 
@@ -286,6 +301,7 @@ YFS_API int yfs_conv2d_dgrad_bf16(const void* dz, const void* wt, const void* x_
     g.OH = H; g.OW = W; g.NOUT = Cin;
     g.KS = K; g.s_mul = 1; g.pad = K - 1 - pad; g.dil = stride; g.slope = slope;
     g.M = (int)(N * H * W);
+    g.xbytes = (unsigned)(N * g.H * g.W * Cout * 2); g.wbytes = (unsigned)((int64_t)Cout * K * K * Cin * 2);
     hipStream_t s = (hipStream_t)stream;
     if (stride == 1) {
         return x_act ? dispatch_igemm<EPI_MASK, false>(g, s, "yfs_conv2d_dgrad_bf16")
@@ -318,6 +334,7 @@ struct WgradArgs {
     const bf16_t* x;    // [N,H,W,Cin]
     float* partial;     // [splits][Cout][taps*Cin]
     int H, W, Cin, OH, OW, Cout, KS, stride, pad, M;
+    unsigned xbytes, zbytes;
     int cotiles, citiles, splits, ktiles, ktiles_per_split;
     FastDiv div_ohw, div_ow;
 };
@@ -358,7 +375,8 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
     if (kt1 > g.ktiles) kt1 = g.ktiles;
 
     const int p_lo = lane & 7, c_lo = lane >> 3;
-    bf16x8 rx[LX], rz[LZ];
+    const __amdgpu_buffer_rsrc_t srx = make_rsrc(g.x, g.xbytes), srz = make_rsrc(g.dz, g.zbytes);
+    u32x4 rx[LX], rz[LZ];
 
     auto load_tile = [&](int kt) {
         const int mbase = kt * 64;
@@ -367,26 +385,20 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
             const int idx = wave * LZ + i;
             const int pixel = (idx / GZ) * 8 + p_lo, ch = ((idx % GZ) * 8 + c_lo) * 8;
             const int m = mbase + pixel;
-            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (m < g.M) v = *reinterpret_cast<const bf16x8*>(g.dz + (long long)m * g.Cout + co0 + ch);
-            rz[i] = v;
+            rz[i] = buf_load16(srz, m < g.M ? ((unsigned)m * (unsigned)g.Cout + (unsigned)(co0 + ch)) * 2u : kOOB);
         }
 #pragma unroll
         for (int i = 0; i < LX; ++i) {
             const int idx = wave * LX + i;
             const int pixel = (idx / GX) * 8 + p_lo, ch = ((idx % GX) * 8 + c_lo) * 8;
             const int m = mbase + pixel;
-            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (m < g.M) {
-                const unsigned n = fdiv((unsigned)m, g.div_ohw);
-                const unsigned rem = (unsigned)m - n * g.div_ohw.d;
-                const unsigned oh = fdiv(rem, g.div_ow);
-                const unsigned ow = rem - oh * g.div_ow.d;
-                const int ih = (int)oh * g.stride - g.pad + kh, iw = (int)ow * g.stride - g.pad + kw;
-                if ((unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W)
-                    v = *reinterpret_cast<const bf16x8*>(g.x + ((long long)(n * g.H + ih) * g.W + iw) * g.Cin + ci0 + ch);
-            }
-            rx[i] = v;
+            const unsigned n = fdiv((unsigned)m, g.div_ohw);
+            const unsigned rem = (unsigned)m - n * g.div_ohw.d;
+            const unsigned oh = fdiv(rem, g.div_ow);
+            const unsigned ow = rem - oh * g.div_ow.d;
+            const int ih = (int)oh * g.stride - g.pad + kh, iw = (int)ow * g.stride - g.pad + kw;
+            const bool ok = m < g.M && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+            rx[i] = buf_load16(srx, ok ? (unsigned)((((int)n * g.H + ih) * g.W + iw) * g.Cin + ci0 + ch) * 2u : kOOB);
         }
     };
     auto store_tile = [&](int buf) {
@@ -395,13 +407,13 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
         for (int i = 0; i < LX; ++i) {
             const int idx = wave * LX + i;
             const int pixel = (idx / GX) * 8 + p_lo, ch = ((idx % GX) * 8 + c_lo) * 8;
-            *reinterpret_cast<bf16x8*>(base + wg_off(pixel, ch)) = rx[i];
+            *reinterpret_cast<u32x4*>(base + wg_off(pixel, ch)) = rx[i];
         }
 #pragma unroll
         for (int i = 0; i < LZ; ++i) {
             const int idx = wave * LZ + i;
             const int pixel = (idx / GZ) * 8 + p_lo, ch = ((idx % GZ) * 8 + c_lo) * 8;
-            *reinterpret_cast<bf16x8*>(base + XBYTES + wg_off(pixel, ch)) = rz[i];
+            *reinterpret_cast<u32x4*>(base + XBYTES + wg_off(pixel, ch)) = rz[i];
         }
     };
 
@@ -590,6 +602,7 @@ YFS_API int yfs_conv2d_wgrad_bf16(const void* x, const void* dz, float* dw, floa
     g.dz = (const bf16_t*)dz; g.x = (const bf16_t*)x; g.partial = (float*)workspace;
     g.H = H; g.W = W; g.Cin = Cin; g.OH = OH; g.OW = OW; g.Cout = Cout; g.KS = K; g.stride = stride; g.pad = pad;
     g.M = (int)M;
+    g.xbytes = (unsigned)(N * H * W * Cin * 2); g.zbytes = (unsigned)(M * Cout * 2);
     g.cotiles = p.cotiles; g.citiles = p.citiles; g.splits = p.splits; g.ktiles = p.ktiles;
     g.ktiles_per_split = p.ktiles_per_split;
     g.div_ohw = make_fastdiv((unsigned)(OH * OW)); g.div_ow = make_fastdiv((unsigned)OW);
