@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Per-layer micro-benchmark of the conv kernel set at BASELINE config 2 shapes (batch 64, 448x448).
+    python tools/conv_bench.py [--ops fwd,dgrad,wgrad] [--layers 2,7,18] [--iters 10] [--batch 64]
+Prints TFLOP/s per layer and op (HIP-event timing, random bf16 data)."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from yolo_from_scratch_amd import conv_ops as co   # noqa: E402
+
+# feat index -> (cin, cout, k, stride, in_hw)
+LAYERS = {0: (192, 192, 1, 1, 224),   # stem after im2col (K padded 147 -> 192)
+          2: (192, 256, 3, 1, 112), 4: (256, 128, 1, 1, 56), 5: (128, 256, 3, 1, 56), 6: (256, 256, 1, 1, 56),
+          7: (256, 512, 3, 1, 56), 9: (512, 256, 1, 1, 28), 10: (256, 512, 3, 1, 28), 17: (512, 512, 1, 1, 28),
+          18: (512, 1024, 3, 1, 28), 20: (1024, 512, 1, 1, 14), 21: (512, 1024, 3, 1, 14), 24: (1024, 1024, 3, 1, 14),
+          25: (1024, 1024, 3, 2, 14), 26: (1024, 1024, 3, 1, 7)}
+COUNT = {0: 1, 2: 1, 4: 1, 5: 1, 6: 1, 7: 1, 9: 4, 10: 4, 17: 1, 18: 1, 20: 2, 21: 2, 24: 1, 25: 1, 26: 2}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ops", default="fwd,dgrad,wgrad")
+    ap.add_argument("--layers", default=",".join(str(k) for k in LAYERS))
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=64)
+    a = ap.parse_args()
+    dev = "cuda:0"
+    tot = {op: 0.0 for op in a.ops.split(",")}
+    for li in [int(v) for v in a.layers.split(",")]:
+        cin, cout, k, s, hw = LAYERS[li]
+        oh, ow = co.out_hw(hw, hw, k, s)
+        x = torch.randn(a.batch, cin, hw, hw, device=dev).to(torch.bfloat16).contiguous(memory_format=co.CL)
+        w = (torch.randn(cout, cin, k, k, device=dev) * 0.05).contiguous(memory_format=co.CL)
+        b = torch.randn(cout, device=dev)
+        w16, wt16 = co.weight_prep(w)
+        dz = torch.randn(a.batch, cout, oh, ow, device=dev).to(torch.bfloat16).contiguous(memory_format=co.CL)
+        flops = 2.0 * a.batch * oh * ow * cout * cin * k * k
+        line = f"L{li:<2d} {cin:4d}->{cout:4d} k{k} s{s} {hw:3d}^2  GF={flops / 1e9:7.1f}"
+        for op in a.ops.split(","):
+            fn = {"fwd": lambda: co.conv_fwd(x, w16, b, s), "dgrad": lambda: co.conv_dgrad(dz, wt16, (hw, hw), s, x_act=x),
+                  "wgrad": lambda: co.conv_wgrad(x, dz, k, s)}[op]
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / a.iters * 1e3
+            tot[op] += us * COUNT[li]
+            line += f" | {op} {us:8.1f} us {flops / us / 1e6:7.1f} TF"
+        print(line, flush=True)
+    print("per-step totals (us):", {k: round(v, 1) for k, v in tot.items()}, "sum", round(sum(tot.values()), 1))
+
+
+if __name__ == "__main__":
+    main()

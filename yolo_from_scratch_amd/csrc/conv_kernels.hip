@@ -374,7 +374,16 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
     int kt1 = kt0 + g.ktiles_per_split;
     if (kt1 > g.ktiles) kt1 = g.ktiles;
 
-    const int p_lo = lane & 7, c_lo = lane >> 3;
+    // staging lane map: 8 consecutive lanes = 4 pixels x the two 16-byte halves of one 16-channel sub-row, i.e.
+    // 128 contiguous LDS bytes per ds_write_b128 lane group (conflict free); lanes 8 apart walk the sub-tiles of
+    // the same pixels, so a wave-instruction reads whole 256-byte (128-channel) pixel rows from HBM.
+    auto stage_coord = [&](int width, int li, int& pixel, int& ch) {
+        const int half_cpp = width / 16;                       // 16-channel sub-rows per pixel
+        const int u = li * 8 + (lane >> 3);
+        const int q = u / half_cpp, sidx = u - q * half_cpp;
+        pixel = q * 4 + ((lane >> 1) & 3);
+        ch = (sidx * 2 + (lane & 1)) * 8;
+    };
     const __amdgpu_buffer_rsrc_t srx = make_rsrc(g.x, g.xbytes), srz = make_rsrc(g.dz, g.zbytes);
     u32x4 rx[LX], rz[LZ];
 
@@ -382,15 +391,15 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
         const int mbase = kt * 64;
 #pragma unroll
         for (int i = 0; i < LZ; ++i) {
-            const int idx = wave * LZ + i;
-            const int pixel = (idx / GZ) * 8 + p_lo, ch = ((idx % GZ) * 8 + c_lo) * 8;
+            int pixel, ch;
+            stage_coord(BZ, wave * LZ + i, pixel, ch);
             const int m = mbase + pixel;
             rz[i] = buf_load16(srz, m < g.M ? ((unsigned)m * (unsigned)g.Cout + (unsigned)(co0 + ch)) * 2u : kOOB);
         }
 #pragma unroll
         for (int i = 0; i < LX; ++i) {
-            const int idx = wave * LX + i;
-            const int pixel = (idx / GX) * 8 + p_lo, ch = ((idx % GX) * 8 + c_lo) * 8;
+            int pixel, ch;
+            stage_coord(BX, wave * LX + i, pixel, ch);
             const int m = mbase + pixel;
             const unsigned n = fdiv((unsigned)m, g.div_ohw);
             const unsigned rem = (unsigned)m - n * g.div_ohw.d;
@@ -405,14 +414,14 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
         unsigned char* base = smem + buf * TILE_BYTES;
 #pragma unroll
         for (int i = 0; i < LX; ++i) {
-            const int idx = wave * LX + i;
-            const int pixel = (idx / GX) * 8 + p_lo, ch = ((idx % GX) * 8 + c_lo) * 8;
+            int pixel, ch;
+            stage_coord(BX, wave * LX + i, pixel, ch);
             *reinterpret_cast<u32x4*>(base + wg_off(pixel, ch)) = rx[i];
         }
 #pragma unroll
         for (int i = 0; i < LZ; ++i) {
-            const int idx = wave * LZ + i;
-            const int pixel = (idx / GZ) * 8 + p_lo, ch = ((idx % GZ) * 8 + c_lo) * 8;
+            int pixel, ch;
+            stage_coord(BZ, wave * LZ + i, pixel, ch);
             *reinterpret_cast<u32x4*>(base + XBYTES + wg_off(pixel, ch)) = rz[i];
         }
     };
