@@ -134,6 +134,21 @@ int yfs_weight_prep_bf16(const float *w, void *w_bf16, void *wt_bf16, int Cout, 
 int yfs_im2col_bf16(const void *x, int x_is_f32, void *cols, int64_t N, int H, int W, int Cin, int K, int stride,
                     int Kpad, void *stream);
 
+/* Stem Conv2D(3, Cout, 7, s=2)  yolo_toy_regressor_torch.py:220 without an im2col matrix: the image is
+ * rearranged once (2x2 space-to-depth of the 3-padded image, 12 -> 16 channels) and the 7x7/s2 convolution
+ * becomes a 4x4/s1 one whose kernel rows are 64 contiguous elements.
+ * yfs_stem_space_to_depth_bf16: x is [N,3,H,W] with arbitrary element strides (NCHW fp32 as the reference
+ *   feeds it, or channels-last bf16); xs [N,Hs,Ws,16] bf16 with 2*Hs >= H+6, 2*Ws >= W+6.
+ * w2 [Cout][4][64] bf16: w2[co][a][b*16 + (dy*2+dx)*3 + c] = w[co][c][2a+dy][2b+dx] (0 where 2a+dy or 2b+dx > 6).
+ * dw2 [Cout][4][64] fp32 in the same arrangement. */
+int yfs_stem_space_to_depth_bf16(const void *x, int x_is_f32, int64_t stride_n, int64_t stride_c, int64_t stride_h,
+                                 int64_t stride_w, void *xs, int64_t N, int H, int W, int Hs, int Ws, void *stream);
+int yfs_conv2d_stem_fwd_bf16(const void *xs, const void *w2, const float *bias, void *y, int64_t N, int Hs, int Ws,
+                             int OH, int OW, int Cout, float slope, void *stream);
+size_t yfs_conv2d_stem_wgrad_workspace_bytes(int64_t N, int OH, int OW, int Cout);
+int yfs_conv2d_stem_wgrad_bf16(const void *xs, const void *dz, float *dw2, float *db, int64_t N, int Hs, int Ws, int OH,
+                               int OW, int Cout, int accumulate, void *workspace, size_t workspace_bytes, void *stream);
+
 /* MaxPool2d(2, 2)  yolo_toy_regressor_torch.py:216 on NHWC bf16.  H, W even. */
 int yfs_maxpool2_fwd_bf16(const void *x, void *y, int64_t N, int H, int W, int C, void *stream);
 /* dx = route(dy) to the first max of each window [* leaky'(x) when fuse_leaky: x is a LeakyReLU output]. */

@@ -124,3 +124,26 @@ def test_stem_im2col_path(golden_dir):
     # the golden output was computed from un-rounded fp32 x and w; bf16 input rounding (2^-9 relative per
     # operand) shows up as an absolute error on outputs that cancel to ~0, hence the wider absolute term
     _close(y, torch.from_numpy(gg["c2_y"]), "im2col vs reference Conv2D(3,8,7,s=2) output", atol_frac=1e-2)
+
+
+@pytest.mark.parametrize("hw,layout", [(32, "nchw_f32"), (64, "nhwc_bf16"), (30, "nchw_f32")])
+def test_stem_space_to_depth_path(hw, layout, golden_dir):
+    """feat.0 = Conv2D(3,192,7,s=2) as a 4x4/s1 conv over the space-to-depth image: forward, weight and bias grads."""
+    g = torch.Generator().manual_seed(hw)
+    x = _bf(torch.rand(2, 3, hw, hw, generator=g))
+    w = _bf((torch.rand(192, 3, 7, 7, generator=g) * 2 - 1) * 0.1)
+    b = torch.rand(192, generator=g) * 0.1
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    y_ref = model_ref.conv_block(x, wr, br, 2)
+    xd = x.to(DEV) if layout == "nchw_f32" else co.nhwc(x.to(DEV), torch.bfloat16)
+    xs = co.stem_space_to_depth(xd)
+    oh, ow, hs, ws = co.stem_geometry(hw, hw)
+    assert tuple(xs.shape) == (2, 16, hs, ws)
+    y = co.stem_fwd(xs, co.stem_weight(co.nhwc(w.to(DEV))), b.to(DEV), oh, ow)
+    _close(y, y_ref.detach(), "stem forward")
+    dz = _bf(torch.randn(y_ref.shape, generator=g))
+    wg, bg = torch.autograd.grad(F.conv2d(x, wr, br, stride=2, padding=3), (wr, br), dz)
+    dw, db = co.stem_wgrad(xs, co.nhwc(dz.to(DEV), torch.bfloat16))
+    _close(dw.view(192, 7, 7, 3).permute(0, 3, 1, 2), wg, "stem wgrad")
+    _close(db, bg, "stem bias grad")

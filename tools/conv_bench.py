@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from yolo_from_scratch_amd import conv_ops as co   # noqa: E402
 
 # feat index -> (cin, cout, k, stride, in_hw)
-LAYERS = {0: (192, 192, 1, 1, 224),   # stem after im2col (K padded 147 -> 192)
+LAYERS = {0: (3, 192, 7, 2, 448),      # stem: space-to-depth + 4x4 implicit GEMM (useful FLOPs quoted)
           2: (192, 256, 3, 1, 112), 4: (256, 128, 1, 1, 56), 5: (128, 256, 3, 1, 56), 6: (256, 256, 1, 1, 56),
           7: (256, 512, 3, 1, 56), 9: (512, 256, 1, 1, 28), 10: (256, 512, 3, 1, 28), 17: (512, 512, 1, 1, 28),
           18: (512, 1024, 3, 1, 28), 20: (1024, 512, 1, 1, 14), 21: (512, 1024, 3, 1, 14), 24: (1024, 1024, 3, 1, 14),
@@ -32,6 +32,34 @@ def main():
     for li in [int(v) for v in a.layers.split(",")]:
         cin, cout, k, s, hw = LAYERS[li]
         oh, ow = co.out_hw(hw, hw, k, s)
+        if li == 0:
+            x = torch.rand(a.batch, 3, hw, hw, device=dev).to(torch.bfloat16).contiguous(memory_format=co.CL)
+            w = (torch.randn(cout, 3, 7, 7, device=dev) * 0.05).contiguous(memory_format=co.CL)
+            b = torch.randn(cout, device=dev)
+            dz = torch.randn(a.batch, cout, oh, ow, device=dev).to(torch.bfloat16).contiguous(memory_format=co.CL)
+            xs = co.stem_space_to_depth(x)
+            w2 = co.stem_weight(w)
+            flops = 2.0 * a.batch * oh * ow * cout * 147
+            line = f"L0     3-> 192 k7 s2 448^2  GF={flops / 1e9:7.1f}"
+            for op, fn in (("s2d", lambda: co.stem_space_to_depth(x)), ("fwd", lambda: co.stem_fwd(xs, w2, b, oh, ow)),
+                           ("wgrad", lambda: co.stem_wgrad(xs, dz))):
+                if op != "s2d" and op not in tot:
+                    continue
+                for _ in range(2):
+                    fn()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.iters):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) / a.iters * 1e3
+                if op in tot:
+                    tot[op] += us
+                line += f" | {op} {us:8.1f} us {flops / us / 1e6:7.1f} TF"
+            print(line, flush=True)
+            continue
         x = torch.randn(a.batch, cin, hw, hw, device=dev).to(torch.bfloat16).contiguous(memory_format=co.CL)
         w = (torch.randn(cout, cin, k, k, device=dev) * 0.05).contiguous(memory_format=co.CL)
         b = torch.randn(cout, device=dev)

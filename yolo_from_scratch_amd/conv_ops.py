@@ -137,3 +137,92 @@ def im2col(x, k, stride, kpad):
                                     L.c_int(h), L.c_int(w), L.c_int(c), L.c_int(k), L.c_int(stride), L.c_int(kpad),
                                     L.stream()), "yfs_im2col_bf16")
     return cols
+
+
+# ---- stem: Conv2D(3, Cout, 7, s=2) through the 2x2 space-to-depth image (no im2col matrix) ----------------------
+_STEM_IDX = {}
+
+
+def stem_geometry(h, w):
+    oh, ow = out_hw(h, w, 7, 2)
+    return oh, ow, oh + 4, ow + 4
+
+
+def stem_space_to_depth(x):
+    """x [N,3,H,W] (fp32 or bf16, any strides) -> xs bf16, logical [N,16,Hs,Ws] channels_last."""
+    L.require_cuda(x)
+    if x.dim() != 4 or x.shape[1] != 3:
+        raise L.YfsError(f"stem expects [N,3,H,W], got {tuple(x.shape)}")
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        x = x.float()
+    n, _, h, w = x.shape
+    _, _, hs, ws = stem_geometry(h, w)
+    xs = _empty_nhwc(n, 16, hs, ws, x.device)
+    sn, sc, sh, sw = x.stride()
+    L.check(L.lib().yfs_stem_space_to_depth_bf16(L.ptr(x), L.c_int(1 if x.dtype == torch.float32 else 0), L.i64(sn),
+                                                 L.i64(sc), L.i64(sh), L.i64(sw), L.ptr(xs), L.i64(n), L.c_int(h),
+                                                 L.c_int(w), L.c_int(hs), L.c_int(ws), L.stream()),
+            "yfs_stem_space_to_depth_bf16")
+    return xs
+
+
+def _stem_index(device):
+    """Flat gather index: w2.view(Cout, 256)[:, k] = w_nhwc.view(Cout, 147)[:, idx[k]] where mask[k]."""
+    key = str(device)
+    if key not in _STEM_IDX:
+        idx = torch.zeros(4, 4, 16, dtype=torch.long)
+        mask = torch.zeros(4, 4, 16, dtype=torch.bool)
+        for a in range(4):
+            for b in range(4):
+                for dy in range(2):
+                    for dx in range(2):
+                        kh, kw = 2 * a + dy, 2 * b + dx
+                        if kh > 6 or kw > 6:
+                            continue
+                        for c in range(3):
+                            e = (dy * 2 + dx) * 3 + c
+                            idx[a, b, e] = (kh * 7 + kw) * 3 + c       # position in [7][7][3]
+                            mask[a, b, e] = True
+        _STEM_IDX[key] = (idx.view(-1).to(device), mask.view(-1).to(device))
+    return _STEM_IDX[key]
+
+
+def stem_weight(w):
+    """fp32 weight logical [Cout,3,7,7] channels_last -> w2 bf16 [Cout, 4*64] (see include/yfs.h)."""
+    cout = w.shape[0]
+    idx, mask = _stem_index(w.device)
+    flat = w.detach().permute(0, 2, 3, 1).reshape(cout, 147)
+    return (flat[:, idx] * mask).to(torch.bfloat16).contiguous()
+
+
+def stem_weight_grad(dw2, cout):
+    """dw2 fp32 [Cout, 256] -> gradient in [Cout, 147] ((kh,kw,c) order): every real weight appears once in w2."""
+    idx, mask = _stem_index(dw2.device)
+    out = torch.zeros(cout, 147, device=dw2.device, dtype=torch.float32)
+    out[:, idx[mask]] = dw2.view(cout, 256)[:, mask]
+    return out
+
+
+def stem_fwd(xs, w2, bias, oh, ow, slope=0.1):
+    n, _, hs, ws = xs.shape
+    cout = w2.shape[0]
+    y = _empty_nhwc(n, cout, oh, ow, xs.device)
+    L.check(L.lib().yfs_conv2d_stem_fwd_bf16(L.ptr(xs), L.ptr(w2), L.ptr(bias), L.ptr(y), L.i64(n), L.c_int(hs), L.c_int(ws),
+                                             L.c_int(oh), L.c_int(ow), L.c_int(cout), L.c_float(slope), L.stream()),
+            "yfs_conv2d_stem_fwd_bf16")
+    return y
+
+
+def stem_wgrad(xs, dz):
+    """-> (dw as [Cout,147] fp32 in (kh,kw,c) order, db [Cout])."""
+    dz = nhwc(dz, torch.bfloat16)
+    n, _, hs, ws = xs.shape
+    cout, oh, ow = dz.shape[1], dz.shape[2], dz.shape[3]
+    dw2 = torch.empty(cout, 256, device=xs.device, dtype=torch.float32)
+    db = torch.empty(cout, device=xs.device, dtype=torch.float32)
+    nbytes = L.lib().yfs_conv2d_stem_wgrad_workspace_bytes(L.i64(n), L.c_int(oh), L.c_int(ow), L.c_int(cout))
+    ws_buf = workspace(nbytes, xs.device)
+    L.check(L.lib().yfs_conv2d_stem_wgrad_bf16(L.ptr(xs), L.ptr(dz), L.ptr(dw2), L.ptr(db), L.i64(n), L.c_int(hs),
+                                               L.c_int(ws), L.c_int(oh), L.c_int(ow), L.c_int(cout), L.c_int(0),
+                                               L.ptr(ws_buf), L.c_size(nbytes), L.stream()), "yfs_conv2d_stem_wgrad_bf16")
+    return stem_weight_grad(dw2, cout), db

@@ -51,7 +51,8 @@ struct IgemmArgs {
     int N, H, W, C;
     int OH, OW, NOUT;
     unsigned xbytes, wbytes;
-    int KS;               // taps = KS*KS
+    int KH, KW;           // taps = KH*KW
+    int PS;               // elements between adjacent pixels of x (== C except for the space-to-depth stem)
     int s_mul, pad, dil;  // src = o*s_mul - pad + k ; dil > 1: src must divide by dil (strided dgrad)
     int M;                // N*OH*OW
     int mtiles, ntiles;
@@ -97,25 +98,25 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(IgemmArgs g) {
             const int oh = rem / g.OW, ow = rem - oh * g.OW;
             bh[i] = oh * g.s_mul - g.pad;
             bw[i] = ow * g.s_mul - g.pad;
-            if (DIL) rowbyte[i] = (unsigned)n * (unsigned)(g.H * g.W * g.C * 2) + chunk * 16;
-            else rowbyte[i] = (unsigned)(((long long)(n * g.H + bh[i]) * g.W + bw[i]) * g.C * 2) + chunk * 16;
+            if (DIL) rowbyte[i] = (unsigned)n * (unsigned)(g.H * g.W * g.PS * 2) + chunk * 16;
+            else rowbyte[i] = (unsigned)(((long long)(n * g.H + bh[i]) * g.W + bw[i]) * g.PS * 2) + chunk * 16;
         } else {
             bh[i] = -(1 << 28);
             bw[i] = -(1 << 28);
             rowbyte[i] = 0;
         }
     }
-    const unsigned ktot = (unsigned)(g.KS * g.KS * g.C);
+    const unsigned ktot = (unsigned)(g.KH * g.KW * g.C);
     const unsigned wrow = (unsigned)(n0 + srow) * ktot * 2 + chunk * 16;
 
     const int cchunks = g.C / BK;
-    const int nit = g.KS * g.KS * cchunks;
+    const int nit = g.KH * g.KW * cchunks;
 
     u32x4 ra[RA], rb[RB];
     int kh = 0, kw = 0, cc = 0;   // position of the NEXT tile to load
 
     auto load_tile = [&](int it) {
-        const unsigned tapoff = (unsigned)(((kh * g.W + kw) * g.C + cc * BK) * 2);
+        const unsigned tapoff = (unsigned)(((kh * g.W + kw) * g.PS + cc * BK) * 2);
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             int sh = bh[i] + kh, sw = bw[i] + kw;
@@ -126,7 +127,7 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(IgemmArgs g) {
                 sh /= g.dil;
                 sw /= g.dil;
                 ok = ok && sh < g.H && sw < g.W;
-                off = rowbyte[i] + (unsigned)(((sh * g.W + sw) * g.C + cc * BK) * 2);
+                off = rowbyte[i] + (unsigned)(((sh * g.W + sw) * g.PS + cc * BK) * 2);
             } else {
                 ok = (unsigned)sh < (unsigned)g.H && (unsigned)sw < (unsigned)g.W;
                 off = rowbyte[i] + tapoff;
@@ -137,7 +138,7 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(IgemmArgs g) {
         for (int i = 0; i < RB; ++i) rb[i] = buf_load16(rw, wrow + (unsigned)(32 * i) * ktot * 2 + (unsigned)it * (BK * 2));
         if (++cc == cchunks) {
             cc = 0;
-            if (++kw == g.KS) { kw = 0; ++kh; }
+            if (++kw == g.KW) { kw = 0; ++kh; }
         }
     };
     auto store_tile = [&](int buf) {
@@ -282,7 +283,7 @@ YFS_API int yfs_conv2d_fwd_bf16(const void* x, const void* w, const float* bias,
     g.x = (const bf16_t*)x; g.w = (const bf16_t*)w; g.bias = bias; g.out = (bf16_t*)y;
     g.N = (int)N; g.H = H; g.W = W; g.C = Cin;
     g.OH = (H + 2 * pad - K) / stride + 1; g.OW = (W + 2 * pad - K) / stride + 1; g.NOUT = Cout;
-    g.KS = K; g.s_mul = stride; g.pad = pad; g.dil = 1; g.slope = slope;
+    g.KH = g.KW = K; g.PS = Cin; g.s_mul = stride; g.pad = pad; g.dil = 1; g.slope = slope;
     g.M = (int)(N * g.OH * g.OW);
     g.xbytes = (unsigned)(N * H * W * Cin * 2); g.wbytes = (unsigned)((int64_t)Cout * K * K * Cin * 2);
     return dispatch_igemm<EPI_BIAS_LEAKY, false>(g, (hipStream_t)stream, "yfs_conv2d_fwd_bf16");
@@ -299,7 +300,7 @@ YFS_API int yfs_conv2d_dgrad_bf16(const void* dz, const void* wt, const void* x_
     g.N = (int)N;
     g.H = (H + 2 * pad - K) / stride + 1; g.W = (W + 2 * pad - K) / stride + 1; g.C = Cout;   // gathered tensor = dz
     g.OH = H; g.OW = W; g.NOUT = Cin;
-    g.KS = K; g.s_mul = 1; g.pad = K - 1 - pad; g.dil = stride; g.slope = slope;
+    g.KH = g.KW = K; g.PS = Cout; g.s_mul = 1; g.pad = K - 1 - pad; g.dil = stride; g.slope = slope;
     g.M = (int)(N * H * W);
     g.xbytes = (unsigned)(N * g.H * g.W * Cout * 2); g.wbytes = (unsigned)((int64_t)Cout * K * K * Cin * 2);
     hipStream_t s = (hipStream_t)stream;
@@ -333,7 +334,7 @@ struct WgradArgs {
     const bf16_t* dz;   // [M][Cout]
     const bf16_t* x;    // [N,H,W,Cin]
     float* partial;     // [splits][Cout][taps*Cin]
-    int H, W, Cin, OH, OW, Cout, KS, stride, pad, M;
+    int H, W, Cin, OH, OW, Cout, KH, KW, PS, stride, pad, M;   // PS: elements between adjacent pixels of x
     unsigned xbytes, zbytes;
     int cotiles, citiles, splits, ktiles, ktiles_per_split;
     FastDiv div_ohw, div_ow;
@@ -358,7 +359,7 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wx = wave >> 1, wz = wave & 1;
-    const int taps = g.KS * g.KS;
+    const int taps = g.KH * g.KW;
     const int tiles = g.cotiles * g.citiles * taps;
     const int logical = xcd_remap(blockIdx.x, tiles * g.splits);
     // consecutive logical ids sweep (tap, ci tile) for a fixed (split, co tile): they re-read one dz slab
@@ -367,7 +368,7 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
     const int rest = logical / inner;
     const int cot = rest % g.cotiles, split = rest / g.cotiles;
     const int tap = tci / g.citiles, cit = tci % g.citiles;
-    const int kh = tap / g.KS, kw = tap % g.KS;
+    const int kh = tap / g.KW, kw = tap % g.KW;
     const int co0 = cot * BZ, ci0 = cit * BX;
 
     const int kt0 = split * g.ktiles_per_split;
@@ -407,7 +408,7 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
             const unsigned ow = rem - oh * g.div_ow.d;
             const int ih = (int)oh * g.stride - g.pad + kh, iw = (int)ow * g.stride - g.pad + kw;
             const bool ok = m < g.M && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
-            rx[i] = buf_load16(srx, ok ? (unsigned)((((int)n * g.H + ih) * g.W + iw) * g.Cin + ci0 + ch) * 2u : kOOB);
+            rx[i] = buf_load16(srx, ok ? (unsigned)((((int)n * g.H + ih) * g.W + iw) * g.PS + ci0 + ch) * 2u : kOOB);
         }
     };
     auto store_tile = [&](int buf) {
@@ -546,21 +547,23 @@ struct WgradPlan {
     size_t partial_bytes, db_bytes;
 };
 
-WgradPlan plan_wgrad(int64_t M, int Cin, int Cout, int K) {
+// taps = KH*KW.  Tile widths: 128 where the channel count allows, 192 for the two 192-channel tensors of the
+// backbone (feat.2's input, feat.0's output), else 64.  Only the instantiated (bx, bz) pairs are produced.
+WgradPlan plan_wgrad(int64_t M, int Cin, int Cout, int taps) {
     WgradPlan p;
-    p.bx = (Cin % 128 == 0) ? 128 : 64;
-    p.bz = (Cout % 128 == 0) ? 128 : 64;
+    p.bx = (Cin % 128 == 0) ? 128 : ((Cin % 192 == 0 && Cout % 128 == 0) ? 192 : 64);
+    p.bz = (Cout % 128 == 0) ? 128 : ((Cout % 192 == 0 && p.bx == 64) ? 192 : 64);
     p.citiles = Cin / p.bx;
     p.cotiles = Cout / p.bz;
     p.ktiles = (int)yfs_cdiv(M, 64);
-    const int tiles = p.citiles * p.cotiles * K * K;
+    const int tiles = p.citiles * p.cotiles * taps;
     int splits = (int)yfs_cdiv(1024, tiles);              // aim at >= 4 workgroups per CU
     const int max_by_work = p.ktiles / 8 > 0 ? p.ktiles / 8 : 1;   // at least 8 k-tiles (512 pixels) per split
     if (splits > max_by_work) splits = max_by_work;
     if (splits < 1) splits = 1;
     p.ktiles_per_split = (int)yfs_cdiv(p.ktiles, splits);
     p.splits = (int)yfs_cdiv(p.ktiles, p.ktiles_per_split);
-    p.partial_bytes = (size_t)p.splits * Cout * K * K * Cin * sizeof(float);
+    p.partial_bytes = (size_t)p.splits * Cout * taps * Cin * sizeof(float);
     int dbs = (int)yfs_cdiv(M, 2048);
     if (dbs > 256) dbs = 256;
     p.db_splits = dbs;
@@ -576,7 +579,7 @@ int launch_wgrad(WgradArgs& g, const WgradPlan& p, hipStream_t s) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         YFS_REQUIRE(e == hipSuccess, YFS_ERR_LAUNCH, "yfs_conv2d_wgrad_bf16: cannot reserve %zu bytes of LDS", lds);
     }
-    const int nblk = p.cotiles * p.citiles * g.KS * g.KS * p.splits;
+    const int nblk = p.cotiles * p.citiles * g.KH * g.KW * p.splits;
     kern<<<dim3((unsigned)nblk), dim3(kThreads), lds, s>>>(g);
     YFS_CHECK_LAUNCH("wgrad_kernel");
     return YFS_OK;
@@ -588,39 +591,38 @@ YFS_API size_t yfs_conv2d_wgrad_workspace_bytes(int64_t N, int H, int W, int Cin
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || K <= 0 || stride <= 0) return 0;
     const int pad = K / 2;
     const int64_t M = N * ((H + 2 * pad - K) / stride + 1) * ((W + 2 * pad - K) / stride + 1);
-    WgradPlan p = plan_wgrad(M, Cin, Cout, K);
+    WgradPlan p = plan_wgrad(M, Cin, Cout, K * K);
     return p.partial_bytes + p.db_bytes;
 }
 
-YFS_API int yfs_conv2d_wgrad_bf16(const void* x, const void* dz, float* dw, float* db, int64_t N, int H, int W, int Cin,
-                                  int Cout, int K, int stride, int accumulate, void* workspace, size_t workspace_bytes,
-                                  void* stream) {
-    YFS_REQUIRE(x && dz && dw, YFS_ERR_INVALID_ARG, "yfs_conv2d_wgrad_bf16: null pointer");
-    int rc = check_conv_shape("yfs_conv2d_wgrad_bf16", N, H, W, Cin, Cout, K, stride);
-    if (rc) return rc;
-    const int pad = K / 2;
-    const int OH = (H + 2 * pad - K) / stride + 1, OW = (W + 2 * pad - K) / stride + 1;
+namespace {
+// shared by the regular and the stem entry points.  x: pixels PS elements apart, Cin reduced channels per tap.
+int wgrad_common(const char* fn, const void* x, const void* dz, float* dw, float* db, int64_t N, int H, int W, int PS, int Cin,
+                 int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int accumulate, void* workspace,
+                 size_t workspace_bytes, hipStream_t s) {
     const int64_t M = N * OH * OW;
-    WgradPlan p = plan_wgrad(M, Cin, Cout, K);
+    const int taps = KH * KW;
+    WgradPlan p = plan_wgrad(M, Cin, Cout, taps);
     YFS_REQUIRE(workspace && workspace_bytes >= p.partial_bytes + p.db_bytes, YFS_ERR_WORKSPACE,
-                "yfs_conv2d_wgrad_bf16: workspace needs %zu bytes, got %zu", p.partial_bytes + p.db_bytes, workspace_bytes);
-    YFS_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, YFS_ERR_WORKSPACE,
-                "yfs_conv2d_wgrad_bf16: workspace must be 16-byte aligned");
-    hipStream_t s = (hipStream_t)stream;
+                "%s: workspace needs %zu bytes, got %zu", fn, p.partial_bytes + p.db_bytes, workspace_bytes);
+    YFS_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, YFS_ERR_WORKSPACE, "%s: workspace must be 16-byte aligned", fn);
     WgradArgs g = {};
     g.dz = (const bf16_t*)dz; g.x = (const bf16_t*)x; g.partial = (float*)workspace;
-    g.H = H; g.W = W; g.Cin = Cin; g.OH = OH; g.OW = OW; g.Cout = Cout; g.KS = K; g.stride = stride; g.pad = pad;
+    g.H = H; g.W = W; g.Cin = Cin; g.OH = OH; g.OW = OW; g.Cout = Cout; g.KH = KH; g.KW = KW; g.PS = PS; g.stride = stride; g.pad = pad;
     g.M = (int)M;
-    g.xbytes = (unsigned)(N * H * W * Cin * 2); g.zbytes = (unsigned)(M * Cout * 2);
+    g.xbytes = (unsigned)(N * H * W * PS * 2); g.zbytes = (unsigned)(M * Cout * 2);
     g.cotiles = p.cotiles; g.citiles = p.citiles; g.splits = p.splits; g.ktiles = p.ktiles;
     g.ktiles_per_split = p.ktiles_per_split;
     g.div_ohw = make_fastdiv((unsigned)(OH * OW)); g.div_ow = make_fastdiv((unsigned)OW);
+    int rc;
     if (p.bx == 128 && p.bz == 128) rc = launch_wgrad<128, 128>(g, p, s);
-    else if (p.bx == 128) rc = launch_wgrad<128, 64>(g, p, s);
-    else if (p.bz == 128) rc = launch_wgrad<64, 128>(g, p, s);
+    else if (p.bx == 128 && p.bz == 64) rc = launch_wgrad<128, 64>(g, p, s);
+    else if (p.bx == 64 && p.bz == 128) rc = launch_wgrad<64, 128>(g, p, s);
+    else if (p.bx == 192 && p.bz == 128) rc = launch_wgrad<192, 128>(g, p, s);
+    else if (p.bx == 64 && p.bz == 192) rc = launch_wgrad<64, 192>(g, p, s);
     else rc = launch_wgrad<64, 64>(g, p, s);
     if (rc) return rc;
-    const long long n4 = (long long)Cout * K * K * Cin / 4;
+    const long long n4 = (long long)Cout * taps * Cin / 4;
     long long rblk = yfs_cdiv(n4, kThreads);
     if (rblk > 2048) rblk = 2048;
     splitk_reduce_kernel<<<dim3((unsigned)rblk), dim3(kThreads), 0, s>>>((const float4*)workspace, p.splits, n4, (float4*)dw,
@@ -637,6 +639,113 @@ YFS_API int yfs_conv2d_wgrad_bf16(const void* x, const void* dz, float* dw, floa
         YFS_CHECK_LAUNCH("colsum_reduce_kernel");
     }
     return YFS_OK;
+}
+}  // namespace
+
+YFS_API int yfs_conv2d_wgrad_bf16(const void* x, const void* dz, float* dw, float* db, int64_t N, int H, int W, int Cin,
+                                  int Cout, int K, int stride, int accumulate, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+    YFS_REQUIRE(x && dz && dw, YFS_ERR_INVALID_ARG, "yfs_conv2d_wgrad_bf16: null pointer");
+    int rc = check_conv_shape("yfs_conv2d_wgrad_bf16", N, H, W, Cin, Cout, K, stride);
+    if (rc) return rc;
+    const int pad = K / 2;
+    const int OH = (H + 2 * pad - K) / stride + 1, OW = (W + 2 * pad - K) / stride + 1;
+    return wgrad_common("yfs_conv2d_wgrad_bf16", x, dz, dw, db, N, H, W, Cin, Cin, OH, OW, Cout, K, K, stride, pad, accumulate,
+                        workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// ---- stem: Conv2D(3, Cout, 7, s=2) as a 4x4 stride-1 convolution over the 2x2 space-to-depth image ------------
+// xs [N,Hs,Ws,16] bf16 (12 real channels + 4 zero), Hs = Ws = (H+6+1)/2 rounded up to even; one kernel row of
+// the 4x4 window is 4 pixels x 16 channels = 64 contiguous elements = exactly one 128-byte K-chunk, so the
+// implicit GEMM runs with KH=4, KW=1, C=64, pixel stride 16 and never materialises an im2col matrix.
+namespace {
+constexpr int kStemC = 16, kStemKH = 4;
+int stem_check(const char* fn, int64_t N, int Hs, int Ws, int OH, int OW, int Cout) {
+    YFS_REQUIRE(N > 0 && Hs > 0 && Ws > 0 && OH > 0 && OW > 0 && Cout > 0, YFS_ERR_INVALID_ARG, "%s: non-positive dimension", fn);
+    YFS_REQUIRE(OH + 3 <= Hs && OW + 4 <= Ws, YFS_ERR_INVALID_ARG,
+                "%s: space-to-depth image %dx%d too small for a %dx%d output (needs OH+3 rows, OW+4 columns)", fn, Hs, Ws, OH, OW);
+    YFS_REQUIRE(Cout % 64 == 0, YFS_ERR_UNSUPPORTED, "%s: Cout=%d must be a multiple of 64", fn, Cout);
+    YFS_REQUIRE(N * OH * OW * Cout * 2 < 0xFFFFFF00ll && N * Hs * Ws * kStemC * 2 < 0xFFFFFF00ll, YFS_ERR_UNSUPPORTED,
+                "%s: tensor exceeds the 4 GiB range of one buffer descriptor", fn);
+    return YFS_OK;
+}
+
+template <typename TIn>
+__global__ void __launch_bounds__(kThreads) stem_s2d_kernel(const TIn* __restrict__ x, long long sn, long long sc, long long sh,
+                                                            long long sw, bf16_t* __restrict__ out, int H, int W, int Hs, int Ws,
+                                                            long long total) {
+    for (long long id = (long long)blockIdx.x * kThreads + threadIdx.x; id < total; id += (long long)gridDim.x * kThreads) {
+        const int j = (int)(id % Ws);
+        const long long t = id / Ws;
+        const int i = (int)(t % Hs);
+        const long long n = t / Hs;
+        bf16x8 lo = {0, 0, 0, 0, 0, 0, 0, 0}, hi = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {          // q = dy*2 + dx
+            const int ih = 2 * i + (q >> 1) - 3, iw = 2 * j + (q & 1) - 3;
+            if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+                const TIn* p = x + n * sn + ih * sh + iw * sw;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const bf16_t v = (bf16_t)(float)p[c * sc];
+                    const int e = q * 3 + c;
+                    if (e < 8) lo[e] = v; else hi[e - 8] = v;
+                }
+            }
+        }
+        bf16x8* o = reinterpret_cast<bf16x8*>(out + id * kStemC);
+        o[0] = lo;
+        o[1] = hi;
+    }
+}
+}  // namespace
+
+YFS_API int yfs_stem_space_to_depth_bf16(const void* x, int x_is_f32, int64_t stride_n, int64_t stride_c, int64_t stride_h,
+                                         int64_t stride_w, void* xs, int64_t N, int H, int W, int Hs, int Ws, void* stream) {
+    YFS_REQUIRE(x && xs, YFS_ERR_INVALID_ARG, "yfs_stem_space_to_depth_bf16: null pointer");
+    YFS_REQUIRE(N > 0 && H > 0 && W > 0 && 2 * Hs >= H + 6 && 2 * Ws >= W + 6, YFS_ERR_INVALID_ARG,
+                "yfs_stem_space_to_depth_bf16: Hs, Ws must cover the image padded by 3 (2*Hs >= H+6)");
+    const long long total = (long long)N * Hs * Ws;
+    long long blk = yfs_cdiv(total, kThreads);
+    if (blk > 65536) blk = 65536;
+    hipStream_t s = (hipStream_t)stream;
+    if (x_is_f32)
+        stem_s2d_kernel<float><<<dim3((unsigned)blk), dim3(kThreads), 0, s>>>((const float*)x, stride_n, stride_c, stride_h, stride_w,
+                                                                          (bf16_t*)xs, H, W, Hs, Ws, total);
+    else
+        stem_s2d_kernel<bf16_t><<<dim3((unsigned)blk), dim3(kThreads), 0, s>>>((const bf16_t*)x, stride_n, stride_c, stride_h,
+                                                                           stride_w, (bf16_t*)xs, H, W, Hs, Ws, total);
+    YFS_CHECK_LAUNCH("stem_s2d_kernel");
+    return YFS_OK;
+}
+
+YFS_API int yfs_conv2d_stem_fwd_bf16(const void* xs, const void* w2, const float* bias, void* y, int64_t N, int Hs, int Ws, int OH,
+                                     int OW, int Cout, float slope, void* stream) {
+    YFS_REQUIRE(xs && w2 && bias && y, YFS_ERR_INVALID_ARG, "yfs_conv2d_stem_fwd_bf16: null pointer");
+    int rc = stem_check("yfs_conv2d_stem_fwd_bf16", N, Hs, Ws, OH, OW, Cout);
+    if (rc) return rc;
+    IgemmArgs g = {};
+    g.x = (const bf16_t*)xs; g.w = (const bf16_t*)w2; g.bias = bias; g.out = (bf16_t*)y;
+    g.N = (int)N; g.H = Hs; g.W = Ws; g.C = 64; g.PS = kStemC; g.OH = OH; g.OW = OW; g.NOUT = Cout;
+    g.KH = kStemKH; g.KW = 1; g.s_mul = 1; g.pad = 0; g.dil = 1; g.slope = slope;
+    g.M = (int)(N * OH * OW);
+    g.xbytes = (unsigned)(N * Hs * Ws * kStemC * 2); g.wbytes = (unsigned)((int64_t)Cout * kStemKH * 64 * 2);
+    return dispatch_igemm<EPI_BIAS_LEAKY, false>(g, (hipStream_t)stream, "yfs_conv2d_stem_fwd_bf16");
+}
+
+YFS_API size_t yfs_conv2d_stem_wgrad_workspace_bytes(int64_t N, int OH, int OW, int Cout) {
+    if (N <= 0 || OH <= 0 || OW <= 0 || Cout <= 0) return 0;
+    WgradPlan p = plan_wgrad(N * OH * OW, 64, Cout, kStemKH);
+    return p.partial_bytes + p.db_bytes;
+}
+
+YFS_API int yfs_conv2d_stem_wgrad_bf16(const void* xs, const void* dz, float* dw2, float* db, int64_t N, int Hs, int Ws, int OH,
+                                       int OW, int Cout, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    YFS_REQUIRE(xs && dz && dw2, YFS_ERR_INVALID_ARG, "yfs_conv2d_stem_wgrad_bf16: null pointer");
+    int rc = stem_check("yfs_conv2d_stem_wgrad_bf16", N, Hs, Ws, OH, OW, Cout);
+    if (rc) return rc;
+    return wgrad_common("yfs_conv2d_stem_wgrad_bf16", xs, dz, dw2, db, N, Hs, Ws, kStemC, 64, OH, OW, Cout, kStemKH, 1, 1, 0,
+                        accumulate, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 // =============================== helpers ========================================================

@@ -18,7 +18,6 @@ from . import _lib as L
 from . import conv_ops as co
 
 SLOPE = 0.1
-STEM_KPAD = 192   # 7*7*3 = 147 im2col columns padded to a multiple of 64
 
 
 def _pool_fwd(x):
@@ -41,14 +40,6 @@ def _pool_bwd(x, dy, fuse_leaky, slope=SLOPE):
     return dx
 
 
-def _stem_weight(weight):
-    """[Cout,Cin,K,K] (channels_last fp32) -> [Cout, STEM_KPAD, 1, 1] zero-padded im2col weight."""
-    cout, cin, k, _ = weight.shape
-    wk = torch.zeros((cout, STEM_KPAD, 1, 1), device=weight.device, dtype=torch.float32).contiguous(memory_format=co.CL)
-    wk.view(cout, STEM_KPAD)[:, :cin * k * k] = weight.permute(0, 2, 3, 1).reshape(cout, cin * k * k)
-    return wk
-
-
 class _ConvPlan:
     """What one Conv2D block needs in forward and backward; shared by the per-layer and the chained path."""
 
@@ -57,7 +48,10 @@ class _ConvPlan:
         self.k, self.stride, self.cin, self.cout = k, stride, cin, cout
         self.stem = cin % 64 != 0
         if self.stem:
-            self.w16, _ = co.weight_prep(_stem_weight(weight), want_wt16=False)
+            if (cin, k, stride) != (3, 7, 2):
+                raise L.YfsError(f"Conv2D({cin}, {cout}, {k}, s={stride}): Cin must be a multiple of 64 except for "
+                                 "the 3-channel 7x7/s2 stem")
+            self.w16 = co.stem_weight(weight)
             self.wt16 = None
         else:
             self.w16, self.wt16 = co.weight_prep(weight, want_wt16=need_wt)
@@ -66,8 +60,9 @@ class _ConvPlan:
     def forward(self, x):
         """x: NHWC bf16 (or fp32/bf16 image for the stem). Returns (gemm_input, y)."""
         if self.stem:
-            cols = co.im2col(x, self.k, self.stride, STEM_KPAD)
-            return cols, co.conv_fwd(cols, self.w16, self.bias, 1, SLOPE)
+            xs = co.stem_space_to_depth(x)
+            oh, ow, _, _ = co.stem_geometry(x.shape[2], x.shape[3])
+            return xs, co.stem_fwd(xs, self.w16, self.bias, oh, ow, SLOPE)
         x = co.nhwc(x, torch.bfloat16)
         return x, co.conv_fwd(x, self.w16, self.bias, self.stride, SLOPE)
 
@@ -78,9 +73,8 @@ class _ConvPlan:
         wsink = getattr(weight, "_yfs_grad_sink", None)
         bsink = getattr(bias, "_yfs_grad_sink", None)
         if self.stem:
-            dwk, db = co.conv_wgrad(gemm_in, dz, 1, 1)
+            dwv, db = co.stem_wgrad(gemm_in, dz)       # [Cout, 147] in (kh, kw, c) order
             cout, cin, k, _ = weight.shape
-            dwv = dwk.view(cout, STEM_KPAD)[:, :cin * k * k]
 
             def put_w(sink, acc):
                 if sink is None:
