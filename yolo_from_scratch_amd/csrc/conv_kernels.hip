@@ -85,7 +85,12 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(IgemmArgs g) {
     const int m0 = mt * BM, n0 = nt * BN;
 
     // ---- per-thread staging coordinates -------------------------------------------------------
-    const int chunk = tid & 7, srow = tid >> 3;   // 32 rows per pass
+    // Operands go global -> LDS directly (buffer_load ... lds): one wave-instruction writes 64 x 16 B = 8 rows
+    // of 128 B, lane l at base + 16*l.  The XOR swizzle therefore sits on the SOURCE side: lane l (row l>>3 of
+    // the group, LDS slot l&7) fetches global chunk (l&7) ^ (l>>3), which is where swz() expects it.
+    const int srow = tid >> 3;                       // 32 rows per pass, 8 consecutive rows per wave-instruction
+    const int chunk = (lane & 7) ^ (lane >> 3);      // global 16-byte chunk this lane fetches
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.x, g.xbytes), rw = make_rsrc(g.w, g.wbytes);
     int bh[RA], bw[RA];
     unsigned rowbyte[RA];   // byte offset of (n, bh, bw, chunk) — wraps mod 2^32 for negative bh/bw, fixed up by + tap offset
@@ -112,10 +117,11 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(IgemmArgs g) {
     const int cchunks = g.C / BK;
     const int nit = g.KH * g.KW * cchunks;
 
-    u32x4 ra[RA], rb[RB];
-    int kh = 0, kw = 0, cc = 0;   // position of the NEXT tile to load
+    int kh = 0, kw = 0, cc = 0;   // position of the NEXT tile to stage
+    typedef __attribute__((address_space(3))) void* lds_ptr;
 
-    auto load_tile = [&](int it) {
+    auto stage_tile = [&](int it, int buf) {
+        unsigned char* base = smem + buf * TILE_BYTES + wave_u * 1024;
         const unsigned tapoff = (unsigned)(((kh * g.W + kw) * g.PS + cc * BK) * 2);
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
@@ -132,21 +138,16 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(IgemmArgs g) {
                 ok = (unsigned)sh < (unsigned)g.H && (unsigned)sw < (unsigned)g.W;
                 off = rowbyte[i] + tapoff;
             }
-            ra[i] = buf_load16(rx, ok ? off : kOOB);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(base + i * 4096), 16, ok ? off : kOOB, 0, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < RB; ++i) rb[i] = buf_load16(rw, wrow + (unsigned)(32 * i) * ktot * 2 + (unsigned)it * (BK * 2));
+        for (int i = 0; i < RB; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(base + BM * 128 + i * 4096), 16,
+                                                     wrow + (unsigned)(32 * i) * ktot * 2 + (unsigned)it * (BK * 2), 0, 0, 0);
         if (++cc == cchunks) {
             cc = 0;
             if (++kw == g.KW) { kw = 0; ++kh; }
         }
-    };
-    auto store_tile = [&](int buf) {
-        unsigned char* base = smem + buf * TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < RA; ++i) *reinterpret_cast<u32x4*>(base + swz(srow + 32 * i, chunk)) = ra[i];
-#pragma unroll
-        for (int i = 0; i < RB; ++i) *reinterpret_cast<u32x4*>(base + BM * 128 + swz(srow + 32 * i, chunk)) = rb[i];
     };
 
     f32x4 acc[FC][FP];
@@ -155,14 +156,14 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(IgemmArgs g) {
 #pragma unroll
         for (int b = 0; b < FP; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    load_tile(0);
-    store_tile(0);
+    stage_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const int frow = lane & 15, fk = lane >> 4;
     for (int it = 0; it < nit; ++it) {
-        const bool more = it + 1 < nit;
-        if (more) load_tile(it + 1);
+        // the other buffer was last read in iteration it-1 and every wave has passed that iteration's barrier
+        if (it + 1 < nit) stage_tile(it + 1, (it + 1) & 1);
         const unsigned char* pb = smem + (it & 1) * TILE_BYTES;
         const unsigned char* wb = pb + BM * 128;
 #pragma unroll
@@ -180,7 +181,8 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(IgemmArgs g) {
                 for (int b = 0; b < FP; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], pf[b], acc[a][b], 0, 0, 0);
         }
-        if (more) store_tile((it + 1) & 1);
+        // LDS-DMA completion is tracked by vmcnt only; __syncthreads() alone does not wait for it
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
