@@ -342,24 +342,36 @@ struct WgradArgs {
     FastDiv div_ohw, div_ow;
 };
 
-// LDS image of one operand tile: [channel/16][64 pixels][16 channels] bf16, i.e. 32-byte pixel rows
-// inside 2 KiB sub-tiles; address bit 7 is XORed with pixel bit 3 so that the two pixel quads a
-// 32-lane half reads with ds_read_b64_tr_b16 (pixels 8g..8g+3, g = 0,1) fall on disjoint bank halves.
-__device__ __forceinline__ unsigned wg_off(int pixel, int ch /* channel index inside the tile */) {
-    return (unsigned)((ch >> 4) * 2048 + ((pixel * 32) ^ (((pixel >> 3) & 1) << 7)) + (ch & 15) * 2);
+// LDS image of one operand tile: [64 pixels][W channels] bf16, row-major (CPP = W/8 16-byte chunks per pixel
+// row), filled by buffer_load ... lds (lane-linear, so a wave-instruction fetches whole pixel rows from HBM) and
+// read with ds_read_b64_tr_b16.  A 32-lane half of a transposed read touches pixels {8g+4h+q : g=0,1; q=0..3},
+// 32 bytes each; the chunk index is XORed with a function of the pixel so those 8 x 32 B land on disjoint banks:
+//   256-B rows (CPP=16): all rows alias -> 4-bit XOR ((p&3)<<2 | (p>>2)&3)
+//   128-B / 384-B rows (CPP=8, 24): rows alias in pairs -> XOR of the 32-B pair index with (p>>1)&1 | ((p>>3)&1)<<1
+// The XOR is an involution inside an aligned group of 8 (or 16) chunks, applied on the SOURCE side when staging.
+template <int CPP>
+__device__ __forceinline__ int wg_swz(int pixel, int c) {
+    if (CPP == 16) return c ^ (((pixel & 3) << 2) | ((pixel >> 2) & 3));
+    return c ^ ((((pixel >> 1) & 1) | (((pixel >> 3) & 1) << 1)) << 1);
+}
+template <int CPP>
+__device__ __forceinline__ unsigned wg_addr(int pixel, int ch /* channel inside the tile, multiple of 4 */) {
+    return (unsigned)(pixel * (CPP * 16) + wg_swz<CPP>(pixel, ch >> 3) * 16 + (ch & 7) * 2);
 }
 
 // BX = ci tile (MFMA rows), BZ = co tile (MFMA cols).  4 waves as 2 (ci) x 2 (co).
 template <int BX, int BZ>
 __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
     constexpr int FX = BX / 32, FZ = BZ / 32;          // fragments per wave
-    constexpr int GX = BX / 64, GZ = BZ / 64;          // 8-chunk groups per pixel row
-    constexpr int LX = 2 * GX, LZ = 2 * GZ;            // 16-byte loads per thread per tile
+    constexpr int CX = BX / 8, CZ = BZ / 8;            // 16-byte chunks per pixel row
+    constexpr int LX = CX / 4, LZ = CZ / 4;            // LDS-DMA instructions per wave per tile
     constexpr int XBYTES = BX * 128, ZBYTES = BZ * 128;   // 64 pixels * channels * 2 B
     constexpr int TILE_BYTES = XBYTES + ZBYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int wx = wave >> 1, wz = wave & 1;
     const int taps = g.KH * g.KW;
     const int tiles = g.cotiles * g.citiles * taps;
@@ -377,55 +389,43 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
     int kt1 = kt0 + g.ktiles_per_split;
     if (kt1 > g.ktiles) kt1 = g.ktiles;
 
-    // staging lane map: 8 consecutive lanes = 4 pixels x the two 16-byte halves of one 16-channel sub-row, i.e.
-    // 128 contiguous LDS bytes per ds_write_b128 lane group (conflict free); lanes 8 apart walk the sub-tiles of
-    // the same pixels, so a wave-instruction reads whole 256-byte (128-channel) pixel rows from HBM.
-    auto stage_coord = [&](int width, int li, int& pixel, int& ch) {
-        const int half_cpp = width / 16;                       // 16-channel sub-rows per pixel
-        const int u = li * 8 + (lane >> 3);
-        const int q = u / half_cpp, sidx = u - q * half_cpp;
-        pixel = q * 4 + ((lane >> 1) & 3);
-        ch = (sidx * 2 + (lane & 1)) * 8;
-    };
     const __amdgpu_buffer_rsrc_t srx = make_rsrc(g.x, g.xbytes), srz = make_rsrc(g.dz, g.zbytes);
-    u32x4 rx[LX], rz[LZ];
 
-    auto load_tile = [&](int kt) {
+    // per-lane (pixel, source chunk) of each of this wave's LDS-DMA instructions: fixed for the whole K loop
+    int zpix[LZ], zch[LZ], xpix[LX], xch[LX];
+#pragma unroll
+    for (int i = 0; i < LZ; ++i) {
+        const int l = (wave * LZ + i) * 64 + lane;
+        zpix[i] = l / CZ;
+        zch[i] = wg_swz<CZ>(zpix[i], l % CZ) * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < LX; ++i) {
+        const int l = (wave * LX + i) * 64 + lane;
+        xpix[i] = l / CX;
+        xch[i] = wg_swz<CX>(xpix[i], l % CX) * 8;
+    }
+
+    auto stage_tile = [&](int kt, int buf) {
         const int mbase = kt * 64;
+        unsigned char* base = smem + buf * TILE_BYTES;
 #pragma unroll
         for (int i = 0; i < LZ; ++i) {
-            int pixel, ch;
-            stage_coord(BZ, wave * LZ + i, pixel, ch);
-            const int m = mbase + pixel;
-            rz[i] = buf_load16(srz, m < g.M ? ((unsigned)m * (unsigned)g.Cout + (unsigned)(co0 + ch)) * 2u : kOOB);
+            const int m = mbase + zpix[i];
+            const unsigned off = m < g.M ? ((unsigned)m * (unsigned)g.Cout + (unsigned)(co0 + zch[i])) * 2u : kOOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srz, (lds_ptr)(base + XBYTES + (wave_u * LZ + i) * 1024), 16, off, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < LX; ++i) {
-            int pixel, ch;
-            stage_coord(BX, wave * LX + i, pixel, ch);
-            const int m = mbase + pixel;
+            const int m = mbase + xpix[i];
             const unsigned n = fdiv((unsigned)m, g.div_ohw);
             const unsigned rem = (unsigned)m - n * g.div_ohw.d;
             const unsigned oh = fdiv(rem, g.div_ow);
             const unsigned ow = rem - oh * g.div_ow.d;
             const int ih = (int)oh * g.stride - g.pad + kh, iw = (int)ow * g.stride - g.pad + kw;
             const bool ok = m < g.M && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
-            rx[i] = buf_load16(srx, ok ? (unsigned)((((int)n * g.H + ih) * g.W + iw) * g.PS + ci0 + ch) * 2u : kOOB);
-        }
-    };
-    auto store_tile = [&](int buf) {
-        unsigned char* base = smem + buf * TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < LX; ++i) {
-            int pixel, ch;
-            stage_coord(BX, wave * LX + i, pixel, ch);
-            *reinterpret_cast<u32x4*>(base + wg_off(pixel, ch)) = rx[i];
-        }
-#pragma unroll
-        for (int i = 0; i < LZ; ++i) {
-            int pixel, ch;
-            stage_coord(BZ, wave * LZ + i, pixel, ch);
-            *reinterpret_cast<u32x4*>(base + XBYTES + wg_off(pixel, ch)) = rz[i];
+            const unsigned off = ok ? (unsigned)((((int)n * g.H + ih) * g.W + iw) * g.PS + ci0 + xch[i]) * 2u : kOOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srx, (lds_ptr)(base + (wave_u * LX + i) * 1024), 16, off, 0, 0, 0);
         }
     };
 
@@ -441,14 +441,11 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
     const int g4 = lane >> 4, li = lane & 15;
     const int tr_pix = 8 * g4 + (li >> 2), tr_ch = 4 * (li & 3);
 
-    if (kt0 < kt1) {
-        load_tile(kt0);
-        store_tile(0);
-    }
+    if (kt0 < kt1) stage_tile(kt0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kt = kt0; kt < kt1; ++kt) {
-        const bool more = kt + 1 < kt1;
-        if (more) load_tile(kt + 1);
+        if (kt + 1 < kt1) stage_tile(kt + 1, ((kt - kt0) + 1) & 1);
         const unsigned char* xb = smem + ((kt - kt0) & 1) * TILE_BYTES;
         const unsigned char* zb = xb + XBYTES;
 #pragma unroll
@@ -458,18 +455,18 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
             for (int a = 0; a < FX; ++a) {
                 const int ch = wx * (BX / 2) + a * 16 + tr_ch;
                 bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (bf16x4 __attribute__((address_space(3)))*)(xb + wg_off(ks * 32 + tr_pix, ch)));
+                    (bf16x4 __attribute__((address_space(3)))*)(xb + wg_addr<CX>(ks * 32 + tr_pix, ch)));
                 bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (bf16x4 __attribute__((address_space(3)))*)(xb + wg_off(ks * 32 + tr_pix + 4, ch)));
+                    (bf16x4 __attribute__((address_space(3)))*)(xb + wg_addr<CX>(ks * 32 + tr_pix + 4, ch)));
                 xf[a] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
 #pragma unroll
             for (int b = 0; b < FZ; ++b) {
                 const int ch = wz * (BZ / 2) + b * 16 + tr_ch;
                 bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (bf16x4 __attribute__((address_space(3)))*)(zb + wg_off(ks * 32 + tr_pix, ch)));
+                    (bf16x4 __attribute__((address_space(3)))*)(zb + wg_addr<CZ>(ks * 32 + tr_pix, ch)));
                 bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (bf16x4 __attribute__((address_space(3)))*)(zb + wg_off(ks * 32 + tr_pix + 4, ch)));
+                    (bf16x4 __attribute__((address_space(3)))*)(zb + wg_addr<CZ>(ks * 32 + tr_pix + 4, ch)));
                 zf[b] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
 #pragma unroll
@@ -478,7 +475,7 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
                 for (int b = 0; b < FZ; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[a], zf[b], acc[a][b], 0, 0, 0);
         }
-        if (more) store_tile(((kt - kt0) + 1) & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA of the next tile has landed (vmcnt tracks it)
         __syncthreads();
     }
 
