@@ -17,6 +17,7 @@
 //     fragments are read with ds_read_b64_tr_b16 (hardware transpose); split-K over pixels with fp32
 //     partial slabs and a fixed-order reduction (deterministic).
 #include "yfs_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -68,18 +69,28 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 __device__ __forceinline__ unsigned swz(int row, int chunk) { return (unsigned)(row * 128 + ((chunk ^ (row & 7)) << 4)); }
 
-template <int BM, int BN, int EPI, bool DIL>
-__global__ void __launch_bounds__(kThreads, 2) igemm_kernel(IgemmArgs g) {
-    constexpr int FP = BM / 32;   // pixel fragments per wave   (wave tile BM/2 x BN/2)
-    constexpr int FC = BN / 32;   // channel fragments per wave
-    constexpr int RA = BM / 32;   // staged rows per thread, pixel tile
-    constexpr int RB = BN / 32;   // staged rows per thread, weight tile
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// BM pixels x BN channels per workgroup, WM x WN waves (wave tile BM/WM x BN/WN), STAGES-deep LDS ring.
+//   <128,128,2,2,2>: 4 waves, 64 KiB ring, 2 workgroups per CU (the other workgroup covers the barrier waits)
+//   <256,128,4,2,3>: 8 waves, 144 KiB ring, 1 workgroup per CU: 1/3 less L2->LDS traffic per FLOP (the 128x128
+//                    tile needs ~31 TB/s from L2 for 2 PFLOP/s, i.e. all of it), loads get two K-steps to land
+//                    (counted vmcnt: the newest tile stays in flight across the barrier)
+template <int BM, int BN, int WM, int WN, int STAGES, int EPI, bool DIL>
+__global__ void __launch_bounds__(64 * WM * WN, 2) igemm_kernel(IgemmArgs g) {
+    constexpr int NW = WM * WN, NT = 64 * NW;
+    constexpr int FP = BM / WM / 16;   // pixel fragments per wave
+    constexpr int FC = BN / WN / 16;   // channel fragments per wave
+    constexpr int RA = BM / 8 / NW;    // LDS-DMA instructions per wave per tile, pixel operand (8 rows each)
+    constexpr int RB = BN / 8 / NW;    // ... weight operand
     constexpr int TILE_BYTES = (BM + BN) * 128;
     constexpr int EPI_STRIDE = BN * 4 + 16;
+    static_assert(RA >= 1 && RB >= 1 && STAGES >= 2 && STAGES <= 3, "unsupported igemm configuration");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int logical = xcd_remap(blockIdx.x, g.mtiles * g.ntiles);
     const int nt = logical % g.ntiles, mt = logical / g.ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
@@ -88,7 +99,6 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(IgemmArgs g) {
     // Operands go global -> LDS directly (buffer_load ... lds): one wave-instruction writes 64 x 16 B = 8 rows
     // of 128 B, lane l at base + 16*l.  The XOR swizzle therefore sits on the SOURCE side: lane l (row l>>3 of
     // the group, LDS slot l&7) fetches global chunk (l&7) ^ (l>>3), which is where swz() expects it.
-    const int srow = tid >> 3;                       // 32 rows per pass, 8 consecutive rows per wave-instruction
     const int chunk = (lane & 7) ^ (lane >> 3);      // global 16-byte chunk this lane fetches
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.x, g.xbytes), rw = make_rsrc(g.w, g.wbytes);
@@ -96,7 +106,7 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(IgemmArgs g) {
     unsigned rowbyte[RA];   // byte offset of (n, bh, bw, chunk) — wraps mod 2^32 for negative bh/bw, fixed up by + tap offset
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-        const int m = m0 + srow + 32 * i;
+        const int m = m0 + (wave * RA + i) * 8 + (lane >> 3);
         if (m < g.M) {
             const int n = m / (g.OH * g.OW);
             const int rem = m - n * (g.OH * g.OW);
@@ -112,7 +122,7 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(IgemmArgs g) {
         }
     }
     const unsigned ktot = (unsigned)(g.KH * g.KW * g.C);
-    const unsigned wrow = (unsigned)(n0 + srow) * ktot * 2 + chunk * 16;
+    const unsigned wrow = (unsigned)(n0 + wave * RB * 8 + (lane >> 3)) * ktot * 2 + chunk * 16;
 
     const int cchunks = g.C / BK;
     const int nit = g.KH * g.KW * cchunks;
@@ -121,7 +131,7 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(IgemmArgs g) {
     typedef __attribute__((address_space(3))) void* lds_ptr;
 
     auto stage_tile = [&](int it, int buf) {
-        unsigned char* base = smem + buf * TILE_BYTES + wave_u * 1024;
+        unsigned char* base = smem + buf * TILE_BYTES;
         const unsigned tapoff = (unsigned)(((kh * g.W + kw) * g.PS + cc * BK) * 2);
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
@@ -138,12 +148,12 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(IgemmArgs g) {
                 ok = (unsigned)sh < (unsigned)g.H && (unsigned)sw < (unsigned)g.W;
                 off = rowbyte[i] + tapoff;
             }
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(base + i * 4096), 16, ok ? off : kOOB, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(base + (wave_u * RA + i) * 1024), 16, ok ? off : kOOB, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(base + BM * 128 + i * 4096), 16,
-                                                     wrow + (unsigned)(32 * i) * ktot * 2 + (unsigned)it * (BK * 2), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(base + BM * 128 + (wave_u * RB + i) * 1024), 16,
+                                                     wrow + (unsigned)(8 * i) * ktot * 2 + (unsigned)it * (BK * 2), 0, 0, 0);
         if (++cc == cchunks) {
             cc = 0;
             if (++kw == g.KW) { kw = 0; ++kh; }
@@ -156,35 +166,41 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(IgemmArgs g) {
 #pragma unroll
         for (int b = 0; b < FP; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    stage_tile(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < STAGES - 1; ++st)
+        if (st < nit) stage_tile(st, st);
 
     const int frow = lane & 15, fk = lane >> 4;
+    int cur = 0, nxt = STAGES - 1;   // ring slots of tile `it` and of tile `it + STAGES - 1`
     for (int it = 0; it < nit; ++it) {
-        // the other buffer was last read in iteration it-1 and every wave has passed that iteration's barrier
-        if (it + 1 < nit) stage_tile(it + 1, (it + 1) & 1);
-        const unsigned char* pb = smem + (it & 1) * TILE_BYTES;
+        // Tile `it` must have landed.  LDS-DMA completion is tracked by vmcnt only (in issue order), so with a
+        // 3-deep ring the RA+RB loads of tile it+1 may stay in flight; __syncthreads() alone waits for nothing.
+        if (STAGES == 3 && it + 1 < nit) wait_vmcnt<RA + RB>();
+        else wait_vmcnt<0>();
+        // after this barrier every wave has finished reading the slot that is restaged next (it was tile it-1's)
+        __syncthreads();
+        if (it + STAGES - 1 < nit) stage_tile(it + STAGES - 1, nxt);
+        const unsigned char* pb = smem + cur * TILE_BYTES;
         const unsigned char* wb = pb + BM * 128;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 wf[FC], pf[FP];
 #pragma unroll
             for (int a = 0; a < FC; ++a)
-                wf[a] = *reinterpret_cast<const bf16x8*>(wb + swz(wn * (BN / 2) + a * 16 + frow, ks * 4 + fk));
+                wf[a] = *reinterpret_cast<const bf16x8*>(wb + swz(wn * (BN / WN) + a * 16 + frow, ks * 4 + fk));
 #pragma unroll
             for (int b = 0; b < FP; ++b)
-                pf[b] = *reinterpret_cast<const bf16x8*>(pb + swz(wm * (BM / 2) + b * 16 + frow, ks * 4 + fk));
+                pf[b] = *reinterpret_cast<const bf16x8*>(pb + swz(wm * (BM / WM) + b * 16 + frow, ks * 4 + fk));
 #pragma unroll
             for (int a = 0; a < FC; ++a)
 #pragma unroll
                 for (int b = 0; b < FP; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], pf[b], acc[a][b], 0, 0, 0);
         }
-        // LDS-DMA completion is tracked by vmcnt only; __syncthreads() alone does not wait for it
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        cur = cur + 1 == STAGES ? 0 : cur + 1;
+        nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
     }
+    __syncthreads();   // all waves done with the ring before the epilogue reuses it
 
     // ---- epilogue: fp32 tile through LDS, then coalesced 16 B stores ---------------------------
     // acc[a][b][r] = out[pixel = wm*BM/2 + b*16 + (lane&15)][chan = wn*BN/2 + a*16 + (lane>>4)*4 + r]
@@ -192,13 +208,13 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(IgemmArgs g) {
     for (int a = 0; a < FC; ++a)
 #pragma unroll
         for (int b = 0; b < FP; ++b) {
-            const int prow = wm * (BM / 2) + b * 16 + frow;
-            const int ch = wn * (BN / 2) + a * 16 + fk * 4;
+            const int prow = wm * (BM / WM) + b * 16 + frow;
+            const int ch = wn * (BN / WN) + a * 16 + fk * 4;
             *reinterpret_cast<f32x4*>(smem + prow * EPI_STRIDE + ch * 4) = acc[a][b];
         }
     __syncthreads();
     constexpr int TPR = BN / 8;            // threads per output row (8 channels each)
-    constexpr int RPP = kThreads / TPR;    // rows per pass
+    constexpr int RPP = NT / TPR;          // rows per pass
     const int ec = (tid % TPR) * 8, er = tid / TPR;
     float bv[8];
     if (EPI == EPI_BIAS_LEAKY) {
@@ -232,32 +248,215 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(IgemmArgs g) {
     }
 }
 
-template <int BM, int BN>
-constexpr size_t igemm_lds_bytes() {
-    size_t stage = 2 * (size_t)(BM + BN) * 128;
-    size_t epi = (size_t)BM * (BN * 4 + 16);
-    return stage > epi ? stage : epi;
+// ---- high-occupancy variant: 32-deep K-steps, 34 KiB of LDS, four workgroups (16 waves) per CU ---------------
+// Same tile (BM x BN, 2x2 waves of 64x64) but the ring holds 64-byte rows (BK = 32 = one MFMA K-step), so a
+// workgroup needs 2 x 16 KiB instead of 2 x 32 KiB and the epilogue runs in two 64-row passes; with 115 VGPRs
+// four workgroups fit per CU and the hardware scheduler covers barrier and load waits with other workgroups.
+// LDS row = 4 chunks of 16 B; chunk c of row r sits in slot c ^ g((r>>2)&3), g = (0,3,2,1): with the
+// ds_read_b128 lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} every group then covers 16 distinct slots of
+// a 256-byte bank row (the plain XOR with (r>>2)&3 collides rows 0-3 with rows 4-7 of the neighbouring chunk).
+__device__ __forceinline__ unsigned swz32(int row, int chunk) {
+    return (unsigned)(row * 64 + ((chunk ^ ((0 - (row >> 2)) & 3)) << 4));
 }
 
 template <int BM, int BN, int EPI, bool DIL>
-int launch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
+__global__ void __launch_bounds__(kThreads, 4) igemm32_kernel(IgemmArgs g) {
+    constexpr int WM = 2, WN = 2, KT = 32;
+    constexpr int FP = BM / WM / 16, FC = BN / WN / 16;
+    constexpr int RA = BM / 16 / 4, RB = BN / 16 / 4;   // LDS-DMA instructions per wave per tile (16 rows of 64 B each)
+    constexpr int TILE_BYTES = (BM + BN) * 64;
+    constexpr int EPI_STRIDE = BN * 4 + 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int logical = xcd_remap(blockIdx.x, g.mtiles * g.ntiles);
+    const int nt = logical % g.ntiles, mt = logical / g.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // lane l of a wave-instruction: row l>>2 of its 16-row group, LDS slot l&3 -> source chunk (l&3) ^ g(l>>4)
+    const int chunk = (lane & 3) ^ ((0 - (lane >> 4)) & 3);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.x, g.xbytes), rw = make_rsrc(g.w, g.wbytes);
+    int bh[RA], bw[RA];
+    unsigned rowbyte[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int m = m0 + (wave * RA + i) * 16 + (lane >> 2);
+        if (m < g.M) {
+            const int n = m / (g.OH * g.OW);
+            const int rem = m - n * (g.OH * g.OW);
+            const int oh = rem / g.OW, ow = rem - oh * g.OW;
+            bh[i] = oh * g.s_mul - g.pad;
+            bw[i] = ow * g.s_mul - g.pad;
+            if (DIL) rowbyte[i] = (unsigned)n * (unsigned)(g.H * g.W * g.PS * 2) + chunk * 16;
+            else rowbyte[i] = (unsigned)(((long long)(n * g.H + bh[i]) * g.W + bw[i]) * g.PS * 2) + chunk * 16;
+        } else {
+            bh[i] = -(1 << 28);
+            bw[i] = -(1 << 28);
+            rowbyte[i] = 0;
+        }
+    }
+    const unsigned ktot = (unsigned)(g.KH * g.KW * g.C);
+    const unsigned wrow = (unsigned)(n0 + wave * RB * 16 + (lane >> 2)) * ktot * 2 + chunk * 16;
+    const int cchunks = g.C / KT;
+    const int nit = g.KH * g.KW * cchunks;
+    int kh = 0, kw = 0, cc = 0;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+
+    auto stage_tile = [&](int it, int buf) {
+        unsigned char* base = smem + buf * TILE_BYTES;
+        const unsigned tapoff = (unsigned)(((kh * g.W + kw) * g.PS + cc * KT) * 2);
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            int sh = bh[i] + kh, sw = bw[i] + kw;
+            unsigned off;
+            bool ok;
+            if (DIL) {
+                ok = sh >= 0 && sw >= 0 && (sh % g.dil) == 0 && (sw % g.dil) == 0;
+                sh /= g.dil;
+                sw /= g.dil;
+                ok = ok && sh < g.H && sw < g.W;
+                off = rowbyte[i] + (unsigned)(((sh * g.W + sw) * g.PS + cc * KT) * 2);
+            } else {
+                ok = (unsigned)sh < (unsigned)g.H && (unsigned)sw < (unsigned)g.W;
+                off = rowbyte[i] + tapoff;
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(base + (wave_u * RA + i) * 1024), 16, ok ? off : kOOB, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(base + BM * 64 + (wave_u * RB + i) * 1024), 16,
+                                                     wrow + (unsigned)(16 * i) * ktot * 2 + (unsigned)it * (KT * 2), 0, 0, 0);
+        if (++cc == cchunks) {
+            cc = 0;
+            if (++kw == g.KW) { kw = 0; ++kh; }
+        }
+    };
+
+    f32x4 acc[FC][FP];
+#pragma unroll
+    for (int a = 0; a < FC; ++a)
+#pragma unroll
+        for (int b = 0; b < FP; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    stage_tile(0, 0);
+    const int frow = lane & 15, fk = lane >> 4;
+    for (int it = 0; it < nit; ++it) {
+        wait_vmcnt<0>();
+        __syncthreads();
+        if (it + 1 < nit) stage_tile(it + 1, (it + 1) & 1);
+        const unsigned char* pb = smem + (it & 1) * TILE_BYTES;
+        const unsigned char* wb = pb + BM * 64;
+        bf16x8 wf[FC], pf[FP];
+#pragma unroll
+        for (int a = 0; a < FC; ++a) wf[a] = *reinterpret_cast<const bf16x8*>(wb + swz32(wn * (BN / WN) + a * 16 + frow, fk));
+#pragma unroll
+        for (int b = 0; b < FP; ++b) pf[b] = *reinterpret_cast<const bf16x8*>(pb + swz32(wm * (BM / WM) + b * 16 + frow, fk));
+#pragma unroll
+        for (int a = 0; a < FC; ++a)
+#pragma unroll
+            for (int b = 0; b < FP; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], pf[b], acc[a][b], 0, 0, 0);
+    }
+    __syncthreads();
+
+    // ---- epilogue in WM passes of BM/WM rows (keeps LDS at 34 KiB) ------------------------------
+    constexpr int TPR = BN / 8;
+    constexpr int RPP = kThreads / TPR;
+    constexpr int PROWS = BM / WM;
+    const int ec = (tid % TPR) * 8, er = tid / TPR;
+    float bv[8];
+    if (EPI == EPI_BIAS_LEAKY) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bv[j] = g.bias[n0 + ec + j];
+    }
+#pragma unroll
+    for (int pass = 0; pass < WM; ++pass) {
+        if (wm == pass) {
+#pragma unroll
+            for (int a = 0; a < FC; ++a)
+#pragma unroll
+                for (int b = 0; b < FP; ++b) {
+                    const int prow = b * 16 + frow;
+                    const int ch = wn * (BN / WN) + a * 16 + fk * 4;
+                    *reinterpret_cast<f32x4*>(smem + prow * EPI_STRIDE + ch * 4) = acc[a][b];
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < PROWS / RPP; ++p) {
+            const int row = er + p * RPP;
+            const int m = m0 + pass * PROWS + row;
+            if (m >= g.M) continue;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(smem + row * EPI_STRIDE + ec * 4);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(smem + row * EPI_STRIDE + ec * 4 + 16);
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            const long long o = (long long)m * g.NOUT + n0 + ec;
+            if (EPI == EPI_BIAS_LEAKY) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float t = v[j] + bv[j];
+                    v[j] = t > 0.0f ? t : t * g.slope;
+                }
+            } else if (EPI == EPI_MASK) {
+                const bf16x8 av = *reinterpret_cast<const bf16x8*>(g.act + o);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (float)av[j] > 0.0f ? v[j] : v[j] * g.slope;
+            }
+            bf16x8 ov;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ov[j] = (bf16_t)v[j];
+            *reinterpret_cast<bf16x8*>(g.out + o) = ov;
+        }
+        __syncthreads();
+    }
+}
+
+template <int BM, int BN, int EPI, bool DIL>
+int launch_igemm32(IgemmArgs& g, hipStream_t s, const char* name) {
     g.mtiles = (int)yfs_cdiv(g.M, BM);
     g.ntiles = g.NOUT / BN;
-    const size_t lds = igemm_lds_bytes<BM, BN>();
-    auto kern = igemm_kernel<BM, BN, EPI, DIL>;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        YFS_REQUIRE(e == hipSuccess, YFS_ERR_LAUNCH, "%s: cannot reserve %zu bytes of LDS", name, lds);
-    }
-    kern<<<dim3((unsigned)(g.mtiles * g.ntiles)), dim3(kThreads), lds, s>>>(g);
+    size_t stage = 2 * (size_t)(BM + BN) * 64, epi = (size_t)(BM / 2) * (BN * 4 + 16);
+    const size_t lds = stage > epi ? stage : epi;
+    igemm32_kernel<BM, BN, EPI, DIL><<<dim3((unsigned)(g.mtiles * g.ntiles)), dim3(kThreads), lds, s>>>(g);
     YFS_CHECK_LAUNCH(name);
     return YFS_OK;
 }
 
+template <int BM, int BN, int STAGES>
+constexpr size_t igemm_lds_bytes() {
+    size_t stage = (size_t)STAGES * (BM + BN) * 128;
+    size_t epi = (size_t)BM * (BN * 4 + 16);
+    return stage > epi ? stage : epi;
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES, int EPI, bool DIL>
+int launch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
+    g.mtiles = (int)yfs_cdiv(g.M, BM);
+    g.ntiles = g.NOUT / BN;
+    const size_t lds = igemm_lds_bytes<BM, BN, STAGES>();
+    auto kern = igemm_kernel<BM, BN, WM, WN, STAGES, EPI, DIL>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        YFS_REQUIRE(e == hipSuccess, YFS_ERR_LAUNCH, "%s: cannot reserve %zu bytes of LDS", name, lds);
+    }
+    kern<<<dim3((unsigned)(g.mtiles * g.ntiles)), dim3(64 * WM * WN), lds, s>>>(g);
+    YFS_CHECK_LAUNCH(name);
+    return YFS_OK;
+}
+
+// Tile choice (measured on MI355X, batch 64, tools/conv_bench.py): 128x128 / 4 waves / 2-stage 64-deep ring at two
+// workgroups per CU is the fastest on every backbone layer (L7 1015, L18 1097 TFLOP/s); 256x128 / 8 waves / 3 stages
+// (one per CU) reaches 875-990 and the 32-deep four-per-CU variant 790-880, so neither is selected by default.
+// 128x64 serves the 192-channel outputs.  YFS_IGEMM_TILE=256|32 selects the alternatives for benchmarking.
 template <int EPI, bool DIL>
 int dispatch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
-    if (g.NOUT % 128 == 0) return launch_igemm<128, 128, EPI, DIL>(g, s, name);
-    return launch_igemm<128, 64, EPI, DIL>(g, s, name);
+    if (g.NOUT % 128 != 0) return launch_igemm<128, 64, 2, 2, 2, EPI, DIL>(g, s, name);
+    static const int force = [] { const char* e = getenv("YFS_IGEMM_TILE"); return e ? atoi(e) : 0; }();
+    if (force == 32) return launch_igemm32<128, 128, EPI, DIL>(g, s, name);
+    if (force == 256) return launch_igemm<256, 128, 4, 2, 3, EPI, DIL>(g, s, name);
+    return launch_igemm<128, 128, 2, 2, 2, EPI, DIL>(g, s, name);
 }
 
 int check_conv_shape(const char* fn, int64_t N, int H, int W, int Cin, int Cout, int K, int stride) {
