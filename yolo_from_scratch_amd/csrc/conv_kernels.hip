@@ -259,8 +259,8 @@ __device__ __forceinline__ unsigned swz32(int row, int chunk) {
     return (unsigned)(row * 64 + ((chunk ^ ((0 - (row >> 2)) & 3)) << 4));
 }
 
-template <int BM, int BN, int EPI, bool DIL>
-__global__ void __launch_bounds__(kThreads, 4) igemm32_kernel(IgemmArgs g) {
+template <int BM, int BN, int NS, int EPI, bool DIL>
+__global__ void __launch_bounds__(kThreads, (NS <= 2 ? 4 : 2)) igemm32_kernel(IgemmArgs g) {
     constexpr int WM = 2, WN = 2, KT = 32;
     constexpr int FP = BM / WM / 16, FC = BN / WN / 16;
     constexpr int RA = BM / 16 / 4, RB = BN / 16 / 4;   // LDS-DMA instructions per wave per tile (16 rows of 64 B each)
@@ -304,8 +304,11 @@ __global__ void __launch_bounds__(kThreads, 4) igemm32_kernel(IgemmArgs g) {
     int kh = 0, kw = 0, cc = 0;
     typedef __attribute__((address_space(3))) void* lds_ptr;
 
+    // tiles past the end are still issued (all lanes out of range -> zeros into a ring slot nobody reads) so that
+    // the number of loads in flight, and with it the counted vmcnt below, is the same in every iteration
     auto stage_tile = [&](int it, int buf) {
         unsigned char* base = smem + buf * TILE_BYTES;
+        const bool live = it < nit;
         const unsigned tapoff = (unsigned)(((kh * g.W + kw) * g.PS + cc * KT) * 2);
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
@@ -322,12 +325,12 @@ __global__ void __launch_bounds__(kThreads, 4) igemm32_kernel(IgemmArgs g) {
                 ok = (unsigned)sh < (unsigned)g.H && (unsigned)sw < (unsigned)g.W;
                 off = rowbyte[i] + tapoff;
             }
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(base + (wave_u * RA + i) * 1024), 16, ok ? off : kOOB, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(base + (wave_u * RA + i) * 1024), 16, (ok && live) ? off : kOOB, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(base + BM * 64 + (wave_u * RB + i) * 1024), 16,
-                                                     wrow + (unsigned)(16 * i) * ktot * 2 + (unsigned)it * (KT * 2), 0, 0, 0);
+                                                     live ? wrow + (unsigned)(16 * i) * ktot * 2 + (unsigned)it * (KT * 2) : kOOB, 0, 0, 0);
         if (++cc == cchunks) {
             cc = 0;
             if (++kw == g.KW) { kw = 0; ++kh; }
@@ -340,13 +343,17 @@ __global__ void __launch_bounds__(kThreads, 4) igemm32_kernel(IgemmArgs g) {
 #pragma unroll
         for (int b = 0; b < FP; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    stage_tile(0, 0);
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t) stage_tile(t, t);
     const int frow = lane & 15, fk = lane >> 4;
+    int cur = 0, nxt = NS - 1;
     for (int it = 0; it < nit; ++it) {
-        wait_vmcnt<0>();
-        __syncthreads();
-        if (it + 1 < nit) stage_tile(it + 1, (it + 1) & 1);
-        const unsigned char* pb = smem + (it & 1) * TILE_BYTES;
+        wait_vmcnt<(NS - 2) * (RA + RB)>();   // tile `it` has landed; the NS-2 younger ones stay in flight
+        __syncthreads();                      // ... for every wave, and everyone is done reading slot `nxt`
+        stage_tile(it + NS - 1, nxt);
+        const unsigned char* pb = smem + cur * TILE_BYTES;
+        cur = cur + 1 == NS ? 0 : cur + 1;
+        nxt = nxt + 1 == NS ? 0 : nxt + 1;
         const unsigned char* wb = pb + BM * 64;
         bf16x8 wf[FC], pf[FP];
 #pragma unroll
@@ -359,6 +366,7 @@ __global__ void __launch_bounds__(kThreads, 4) igemm32_kernel(IgemmArgs g) {
             for (int b = 0; b < FP; ++b)
                 acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], pf[b], acc[a][b], 0, 0, 0);
     }
+    wait_vmcnt<0>();
     __syncthreads();
 
     // ---- epilogue in WM passes of BM/WM rows (keeps LDS at 34 KiB) ------------------------------
@@ -413,13 +421,18 @@ __global__ void __launch_bounds__(kThreads, 4) igemm32_kernel(IgemmArgs g) {
     }
 }
 
-template <int BM, int BN, int EPI, bool DIL>
+template <int BM, int BN, int NS, int EPI, bool DIL>
 int launch_igemm32(IgemmArgs& g, hipStream_t s, const char* name) {
     g.mtiles = (int)yfs_cdiv(g.M, BM);
     g.ntiles = g.NOUT / BN;
-    size_t stage = 2 * (size_t)(BM + BN) * 64, epi = (size_t)(BM / 2) * (BN * 4 + 16);
+    size_t stage = NS * (size_t)(BM + BN) * 64, epi = (size_t)(BM / 2) * (BN * 4 + 16);
     const size_t lds = stage > epi ? stage : epi;
-    igemm32_kernel<BM, BN, EPI, DIL><<<dim3((unsigned)(g.mtiles * g.ntiles)), dim3(kThreads), lds, s>>>(g);
+    auto kern = igemm32_kernel<BM, BN, NS, EPI, DIL>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        YFS_REQUIRE(e == hipSuccess, YFS_ERR_LAUNCH, "%s: cannot reserve %zu bytes of LDS", name, lds);
+    }
+    kern<<<dim3((unsigned)(g.mtiles * g.ntiles)), dim3(kThreads), lds, s>>>(g);
     YFS_CHECK_LAUNCH(name);
     return YFS_OK;
 }
@@ -454,7 +467,9 @@ template <int EPI, bool DIL>
 int dispatch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
     if (g.NOUT % 128 != 0) return launch_igemm<128, 64, 2, 2, 2, EPI, DIL>(g, s, name);
     static const int force = [] { const char* e = getenv("YFS_IGEMM_TILE"); return e ? atoi(e) : 0; }();
-    if (force == 32) return launch_igemm32<128, 128, EPI, DIL>(g, s, name);
+    if (force == 32) return launch_igemm32<128, 128, 2, EPI, DIL>(g, s, name);
+    if (force == 324) return launch_igemm32<128, 128, 4, EPI, DIL>(g, s, name);
+    if (force == 325) return launch_igemm32<128, 128, 5, EPI, DIL>(g, s, name);
     if (force == 256) return launch_igemm<256, 128, 4, 2, 3, EPI, DIL>(g, s, name);
     return launch_igemm<128, 128, 2, 2, 2, EPI, DIL>(g, s, name);
 }
@@ -467,7 +482,7 @@ int check_conv_shape(const char* fn, int64_t N, int H, int W, int Cin, int Cout,
     YFS_REQUIRE(Cout % 64 == 0, YFS_ERR_UNSUPPORTED, "%s: Cout=%d must be a multiple of 64", fn, Cout);
     const int pad = K / 2;
     const int64_t Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
-    YFS_REQUIRE(N * Ho * Wo * Cout * 2 < 0xFFFFFF00ll && N * H * W * Cin * 2 < 0xFFFFFF00ll, YFS_ERR_UNSUPPORTED,
+    YFS_REQUIRE(N * Ho * Wo * Cout * 2 < 0xFFF00000ll && N * H * W * Cin * 2 < 0xFFF00000ll, YFS_ERR_UNSUPPORTED,
                 "%s: an activation tensor exceeds the 4 GiB range of one buffer descriptor (split the batch)", fn);
     return YFS_OK;
 }
@@ -590,40 +605,61 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
 
     const __amdgpu_buffer_rsrc_t srx = make_rsrc(g.x, g.xbytes), srz = make_rsrc(g.dz, g.zbytes);
 
-    // per-lane (pixel, source chunk) of each of this wave's LDS-DMA instructions: fixed for the whole K loop
-    int zpix[LZ], zch[LZ], xpix[LX], xch[LX];
+    // Per-lane source of each of this wave's LDS-DMA instructions.  A wave fills 16 pixels of every 64-pixel
+    // k-tile (pixels wave*16 .. +15), CX/CZ lanes per pixel.
+    //   dz: byte offset = zoff[i] + kt * (64 * Cout * 2): linear in kt, and pixels past M fall off the end of the
+    //       descriptor (zeros) by themselves.
+    //   x:  the pixel -> (n, oh, ow) -> input offset map costs two divisions and the padding test; doing that for
+    //       every lane of every load made the loop VALU-bound (140 VALU per 32 MFMA).  Instead lane l computes it
+    //       ONCE for pixel wave*16 + (l&15) of k-tile kt + (l>>4), i.e. for four k-tiles at a time, and the loads
+    //       fetch their pixel's value with ds_bpermute and add their channel-chunk offset.  Invalid pixels carry
+    //       kPixOOB, which stays past the end of the descriptor after that add (tensors are
+    //       < 0xFFF00000 bytes, which also keeps the dz offset of a tail tile from wrapping).
+    constexpr unsigned kPixOOB = 0xFFFF0000u;
+    unsigned zoff[LZ], xchb[LX];
+    int xsrc[LX];
 #pragma unroll
     for (int i = 0; i < LZ; ++i) {
         const int l = (wave * LZ + i) * 64 + lane;
-        zpix[i] = l / CZ;
-        zch[i] = wg_swz<CZ>(zpix[i], l % CZ) * 8;
+        const int pix = l / CZ;
+        zoff[i] = ((unsigned)pix * (unsigned)g.Cout + (unsigned)(co0 + wg_swz<CZ>(pix, l % CZ) * 8)) * 2u;
     }
 #pragma unroll
     for (int i = 0; i < LX; ++i) {
         const int l = (wave * LX + i) * 64 + lane;
-        xpix[i] = l / CX;
-        xch[i] = wg_swz<CX>(xpix[i], l % CX) * 8;
+        const int pix = l / CX;
+        xchb[i] = (unsigned)(wg_swz<CX>(pix, l % CX) * 16);
+        xsrc[i] = (pix - wave * 16) * 4;   // bpermute byte address of the lane holding that pixel (first k-tile of a group)
     }
+    const unsigned tapoff = (unsigned)(((kh - g.pad) * g.W + (kw - g.pad)) * g.PS + ci0) * 2u;   // wraps; added mod 2^32
+    unsigned pixcache = 0;
+    auto pixel_offsets = [&](int ktg) -> unsigned {
+        const int m = (ktg + (lane >> 4)) * 64 + wave * 16 + (lane & 15);
+        const unsigned n = fdiv((unsigned)m, g.div_ohw);
+        const unsigned rem = (unsigned)m - n * g.div_ohw.d;
+        const unsigned oh = fdiv(rem, g.div_ow);
+        const unsigned ow = rem - oh * g.div_ow.d;
+        const int ih = (int)oh * g.stride, iw = (int)ow * g.stride;
+        const bool ok = m < g.M && (unsigned)(ih - g.pad + kh) < (unsigned)g.H && (unsigned)(iw - g.pad + kw) < (unsigned)g.W;
+        return ok ? (unsigned)((((int)n * g.H + ih) * g.W + iw) * g.PS) * 2u + tapoff : kPixOOB;
+    };
 
     auto stage_tile = [&](int kt, int buf) {
-        const int mbase = kt * 64;
         unsigned char* base = smem + buf * TILE_BYTES;
+        const int t = (kt - kt0) & 3;
+        if (t == 0) pixcache = pixel_offsets(kt);
+        const unsigned zk = (unsigned)kt * (unsigned)(64 * 2) * (unsigned)g.Cout;
 #pragma unroll
         for (int i = 0; i < LZ; ++i) {
-            const int m = mbase + zpix[i];
-            const unsigned off = m < g.M ? ((unsigned)m * (unsigned)g.Cout + (unsigned)(co0 + zch[i])) * 2u : kOOB;
+            // (a typed local: with a type-dependent offset expression the host pass re-checks the builtin at
+            //  instantiation, fails silently and drops the kernel's launch stub)
+            const unsigned off = zoff[i] + zk;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(srz, (lds_ptr)(base + XBYTES + (wave_u * LZ + i) * 1024), 16, off, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < LX; ++i) {
-            const int m = mbase + xpix[i];
-            const unsigned n = fdiv((unsigned)m, g.div_ohw);
-            const unsigned rem = (unsigned)m - n * g.div_ohw.d;
-            const unsigned oh = fdiv(rem, g.div_ow);
-            const unsigned ow = rem - oh * g.div_ow.d;
-            const int ih = (int)oh * g.stride - g.pad + kh, iw = (int)ow * g.stride - g.pad + kw;
-            const bool ok = m < g.M && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
-            const unsigned off = ok ? (unsigned)((((int)n * g.H + ih) * g.W + iw) * g.PS + ci0 + xch[i]) * 2u : kOOB;
+            const int src = xsrc[i] + t * 64;
+            const unsigned off = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)pixcache) + xchb[i];
             __builtin_amdgcn_raw_ptr_buffer_load_lds(srx, (lds_ptr)(base + (wave_u * LX + i) * 1024), 16, off, 0, 0, 0);
         }
     };
@@ -863,7 +899,7 @@ int stem_check(const char* fn, int64_t N, int Hs, int Ws, int OH, int OW, int Co
     YFS_REQUIRE(OH + 3 <= Hs && OW + 4 <= Ws, YFS_ERR_INVALID_ARG,
                 "%s: space-to-depth image %dx%d too small for a %dx%d output (needs OH+3 rows, OW+4 columns)", fn, Hs, Ws, OH, OW);
     YFS_REQUIRE(Cout % 64 == 0, YFS_ERR_UNSUPPORTED, "%s: Cout=%d must be a multiple of 64", fn, Cout);
-    YFS_REQUIRE(N * OH * OW * Cout * 2 < 0xFFFFFF00ll && N * Hs * Ws * kStemC * 2 < 0xFFFFFF00ll, YFS_ERR_UNSUPPORTED,
+    YFS_REQUIRE(N * OH * OW * Cout * 2 < 0xFFF00000ll && N * Hs * Ws * kStemC * 2 < 0xFFF00000ll, YFS_ERR_UNSUPPORTED,
                 "%s: tensor exceeds the 4 GiB range of one buffer descriptor", fn);
     return YFS_OK;
 }
