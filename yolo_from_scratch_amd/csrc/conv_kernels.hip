@@ -16,6 +16,7 @@
 //     reduction index (pixel) as the slow axis, so the LDS tiles keep [pixel][channel] rows and the
 //     fragments are read with ds_read_b64_tr_b16 (hardware transpose); split-K over pixels with fp32
 //     partial slabs and a fixed-order reduction (deterministic).
+#include <type_traits>
 #include "yfs_common.h"
 #include <cstdlib>
 
@@ -550,6 +551,7 @@ struct WgradArgs {
     const bf16_t* dz;   // [M][Cout]
     const bf16_t* x;    // [N,H,W,Cin]
     float* partial;     // [splits][Cout][taps*Cin]
+    float* dbpart;      // [splits][taps*citiles][2][Cout] partial column sums of dz (bias gradient), or null
     int H, W, Cin, OH, OW, Cout, KH, KW, PS, stride, pad, M;   // PS: elements between adjacent pixels of x
     unsigned xbytes, zbytes;
     int cotiles, citiles, splits, ktiles, ktiles_per_split;
@@ -676,12 +678,23 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
     const int g4 = lane >> 4, li = lane & 15;
     const int tr_pix = 8 * g4 + (li >> 2), tr_ch = 4 * (li & 3);
 
-    if (kt0 < kt1) stage_tile(kt0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int kt = kt0; kt < kt1; ++kt) {
-        if (kt + 1 < kt1) stage_tile(kt + 1, ((kt - kt0) + 1) & 1);
-        const unsigned char* xb = smem + ((kt - kt0) & 1) * TILE_BYTES;
+    // Bias gradient db[co] = sum over pixels of dz: the dz fragments are already in registers, so the column sum
+    // is one more MFMA against an all-ones operand.  The `inner` workgroups that share a dz slab take every
+    // inner-th k-tile each (and the two wave rows one 32-pixel half each), so the extra MFMAs are spread evenly
+    // (+25 % / inner); every (workgroup, wave row) writes its own partial row, reduced in fixed order afterwards.
+    const bool do_db = g.dbpart != nullptr;
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.0f;
+    f32x4 accdb[FZ];
+#pragma unroll
+    for (int b = 0; b < FZ; ++b) accdb[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int dbc = kt0 % inner;
+
+    // one 64-pixel k-tile; three straight-line copies (MODE is a compile-time tag) so that the column-sum MFMAs
+    // do not put a branch inside the read/MFMA schedule
+    auto tile_mfma = [&](const unsigned char* xb, auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
         const unsigned char* zb = xb + XBYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -709,7 +722,24 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
 #pragma unroll
                 for (int b = 0; b < FZ; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[a], zf[b], acc[a][b], 0, 0, 0);
+            if (MODE == 1 + ks) {
+#pragma unroll
+                for (int b = 0; b < FZ; ++b) accdb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, zf[b], accdb[b], 0, 0, 0);
+            }
         }
+    };
+
+    if (kt0 < kt1) stage_tile(kt0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+        if (kt + 1 < kt1) stage_tile(kt + 1, ((kt - kt0) + 1) & 1);
+        const int mode = (do_db && dbc == tci) ? 1 + wx : 0;   // 0: no column sum; 1 / 2: this wave sums k-half 0 / 1
+        dbc = dbc + 1 == inner ? 0 : dbc + 1;
+        const unsigned char* xb = smem + ((kt - kt0) & 1) * TILE_BYTES;
+        if (mode == 0) tile_mfma(xb, std::integral_constant<int, 0>());
+        else if (mode == 1) tile_mfma(xb, std::integral_constant<int, 1>());
+        else tile_mfma(xb, std::integral_constant<int, 2>());
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA of the next tile has landed (vmcnt tracks it)
         __syncthreads();
     }
@@ -725,6 +755,11 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
             const int ci = ci0 + wx * (BX / 2) + a * 16 + g4 * 4;
             *reinterpret_cast<f32x4*>(pbase + (long long)co * kw_tot + (long long)tap * g.Cin + ci) = acc[a][b];
         }
+    if (do_db && g4 == 0) {   // all 16 rows of accdb are equal: row 0 (lanes 0-15, register 0) is written
+        float* drow = g.dbpart + ((long long)(split * inner + tci) * 2 + wx) * g.Cout;
+#pragma unroll
+        for (int b = 0; b < FZ; ++b) drow[co0 + wz * (BZ / 2) + b * 16 + li] = accdb[b][0];
+    }
 }
 
 // dw[i] = (accumulate ? dw[i] : 0) + sum_s partial[s][i], fixed order over s.
@@ -741,39 +776,34 @@ __global__ void __launch_bounds__(kThreads) splitk_reduce_kernel(const float4* _
     }
 }
 
-// db[co] = sum over pixels of dz[m][co].  Block = 64 channels x 32 row lanes; grid.y splits the rows;
-// partial sums per (row split, channel) are then reduced in fixed order.
-__global__ void __launch_bounds__(kThreads) colsum_kernel(const bf16_t* __restrict__ dz, int M, int C, int rows_per_blk,
-                                                          float* __restrict__ partial) {
-    __shared__ float red[32][64 + 1];
-    const int c8 = threadIdx.x & 7, rl = threadIdx.x >> 3;
-    const int c0 = blockIdx.x * 64 + c8 * 8;
-    const int r0 = blockIdx.y * rows_per_blk;
-    int r1 = r0 + rows_per_blk;
-    if (r1 > M) r1 = M;
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int m = r0 + rl; m < r1; m += 32) {
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(dz + (long long)m * C + c0);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) red[rl][c8 * 8 + j] = acc[j];
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        float s = 0.f;
-        for (int r = 0; r < 32; ++r) s += red[r][threadIdx.x];
-        partial[(long long)blockIdx.y * C + blockIdx.x * 64 + threadIdx.x] = s;
-    }
-}
-
+// db[c] = (accumulate ? db[c] : 0) + sum of the wgrad kernel's partial column-sum rows.  One block per 16
+// channels; 16 row groups (rows r, r+16, ...) per channel are summed independently and combined in fixed order.
 __global__ void __launch_bounds__(kThreads) colsum_reduce_kernel(const float* __restrict__ partial, int nsplit, int C,
                                                                  float* __restrict__ db, int accumulate) {
-    const int c = blockIdx.x * kThreads + threadIdx.x;
-    if (c >= C) return;
-    float s = accumulate ? db[c] : 0.f;
-    for (int k = 0; k < nsplit; ++k) s += partial[(long long)k * C + c];
-    db[c] = s;
+    __shared__ float red[16][16 + 1];
+    const int cl = threadIdx.x & 15, r = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    float s = 0.f;
+    if (c < C) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // four loads in flight; combined in fixed order
+        int k = r;
+        for (; k + 48 < nsplit; k += 64) {
+            s0 += partial[(long long)k * C + c];
+            s1 += partial[(long long)(k + 16) * C + c];
+            s2 += partial[(long long)(k + 32) * C + c];
+            s3 += partial[(long long)(k + 48) * C + c];
+        }
+        for (; k < nsplit; k += 16) s0 += partial[(long long)k * C + c];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    red[r][cl] = s;
+    __syncthreads();
+    if (r == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][cl];
+        db[c] = accumulate ? db[c] + t : t;
+    }
 }
 
 struct WgradPlan {
@@ -791,17 +821,27 @@ WgradPlan plan_wgrad(int64_t M, int Cin, int Cout, int taps) {
     p.cotiles = Cout / p.bz;
     p.ktiles = (int)yfs_cdiv(M, 64);
     const int tiles = p.citiles * p.cotiles * taps;
-    int splits = (int)yfs_cdiv(1024, tiles);              // aim at >= 4 workgroups per CU
-    const int max_by_work = p.ktiles / 8 > 0 ? p.ktiles / 8 : 1;   // at least 8 k-tiles (512 pixels) per split
-    if (splits > max_by_work) splits = max_by_work;
-    if (splits < 1) splits = 1;
-    p.ktiles_per_split = (int)yfs_cdiv(p.ktiles, splits);
+    // Split-K factor: the grid runs in rounds of 512 workgroups (2 per CU), so a block count just above a multiple
+    // of 512 wastes most of a round (L7: 72 tiles x 15 splits = 1080 blocks ran at 70 %).  Pick the factor that
+    // minimises a simple cost model: rounds x (k-tiles per split x time per k-tile + fixed prologue/epilogue)
+    // + the fp32 slab traffic of writing and re-reading `splits` partial copies.  At least 8 k-tiles per split.
+    const int max_splits = p.ktiles / 8 > 0 ? p.ktiles / 8 : 1;
+    const double t_tile = 1.08 * (double)(p.bx * p.bz) / (128.0 * 128.0);            // us per 64-pixel k-tile
+    const double t_slab = (double)Cout * taps * Cin * 8.0 / 4.0e6;                    // us per partial copy (w + r at 4 TB/s)
+    double best = 1e30;
+    int best_per = p.ktiles;
+    for (int sp = 1; sp <= max_splits && sp <= 1024; ++sp) {
+        const int per = (int)yfs_cdiv(p.ktiles, sp);
+        const int real = (int)yfs_cdiv(p.ktiles, per);
+        const long long rounds = yfs_cdiv((long long)tiles * real, 512);
+        const double t = (double)rounds * (per * t_tile + 3.0) + real * t_slab;
+        if (t < best) { best = t; best_per = per; }
+    }
+    p.ktiles_per_split = best_per;
     p.splits = (int)yfs_cdiv(p.ktiles, p.ktiles_per_split);
     p.partial_bytes = (size_t)p.splits * Cout * taps * Cin * sizeof(float);
-    int dbs = (int)yfs_cdiv(M, 2048);
-    if (dbs > 256) dbs = 256;
-    p.db_splits = dbs;
-    p.db_bytes = (size_t)dbs * Cout * sizeof(float);
+    p.db_splits = p.splits * p.citiles * taps * 2;   // one partial row per (split, tap, ci tile, wave row)
+    p.db_bytes = (size_t)p.db_splits * Cout * sizeof(float);
     return p;
 }
 
@@ -842,6 +882,7 @@ int wgrad_common(const char* fn, const void* x, const void* dz, float* dw, float
     YFS_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, YFS_ERR_WORKSPACE, "%s: workspace must be 16-byte aligned", fn);
     WgradArgs g = {};
     g.dz = (const bf16_t*)dz; g.x = (const bf16_t*)x; g.partial = (float*)workspace;
+    g.dbpart = db ? (float*)((unsigned char*)workspace + p.partial_bytes) : nullptr;
     g.H = H; g.W = W; g.Cin = Cin; g.OH = OH; g.OW = OW; g.Cout = Cout; g.KH = KH; g.KW = KW; g.PS = PS; g.stride = stride; g.pad = pad;
     g.M = (int)M;
     g.xbytes = (unsigned)(N * H * W * PS * 2); g.zbytes = (unsigned)(M * Cout * 2);
@@ -864,11 +905,7 @@ int wgrad_common(const char* fn, const void* x, const void* dz, float* dw, float
     YFS_CHECK_LAUNCH("splitk_reduce_kernel");
     if (db) {
         float* dbp = (float*)((unsigned char*)workspace + p.partial_bytes);
-        const int rows_per = (int)yfs_cdiv(M, p.db_splits);
-        colsum_kernel<<<dim3((unsigned)(Cout / 64), (unsigned)p.db_splits), dim3(kThreads), 0, s>>>((const bf16_t*)dz, (int)M, Cout,
-                                                                                             rows_per, dbp);
-        YFS_CHECK_LAUNCH("colsum_kernel");
-        colsum_reduce_kernel<<<dim3((unsigned)yfs_cdiv(Cout, kThreads)), dim3(kThreads), 0, s>>>(dbp, p.db_splits, Cout, db,
+        colsum_reduce_kernel<<<dim3((unsigned)yfs_cdiv(Cout, 16)), dim3(kThreads), 0, s>>>(dbp, p.db_splits, Cout, db,
                                                                                             accumulate);
         YFS_CHECK_LAUNCH("colsum_reduce_kernel");
     }
