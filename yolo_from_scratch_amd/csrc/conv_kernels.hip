@@ -16,6 +16,7 @@
 //     reduction index (pixel) as the slow axis, so the LDS tiles keep [pixel][channel] rows and the
 //     fragments are read with ds_read_b64_tr_b16 (hardware transpose); split-K over pixels with fp32
 //     partial slabs and a fixed-order reduction (deterministic).
+#include <algorithm>
 #include <type_traits>
 #include "yfs_common.h"
 #include <cstdlib>
@@ -55,10 +56,17 @@ struct IgemmArgs {
     unsigned xbytes, wbytes;
     int KH, KW;           // taps = KH*KW
     int PS;               // elements between adjacent pixels of x (== C except for the space-to-depth stem)
-    int s_mul, pad, dil;  // src = o*s_mul - pad + k ; dil > 1: src must divide by dil (strided dgrad)
+    int s_mul, pad;       // src = o*s_mul - pad + k
     int M;                // N*OH*OW
     int mtiles, ntiles;
     float slope;
+    // SUB (dgrad of a stride-s conv): the output pixels are split into s*s parity classes (ih % s, iw % s).  Inside
+    // a class only every s-th tap per axis touches a real dz pixel, and those taps form an ordinary stride-1
+    // gather over the class's own (OH/s x OW/s) grid, so each class is a dense implicit GEMM with ~1/s^2 of the
+    // taps instead of a dilated gather that multiplies zeros 1 - 1/s^2 of the time.
+    int sub_s;                 // s
+    int cls_ph[4], cls_pw[4];  // class parities, heaviest class (most taps) first
+    int cls_end[4];            // running end of each class's logical block range (m-tiles of the class x ntiles)
 };
 
 // XCD-aware, bijective remap: blocks that share blockIdx % 8 share an XCD (and its L2); give each XCD a
@@ -78,7 +86,7 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 //   <256,128,4,2,3>: 8 waves, 144 KiB ring, 1 workgroup per CU: 1/3 less L2->LDS traffic per FLOP (the 128x128
 //                    tile needs ~31 TB/s from L2 for 2 PFLOP/s, i.e. all of it), loads get two K-steps to land
 //                    (counted vmcnt: the newest tile stays in flight across the barrier)
-template <int BM, int BN, int WM, int WN, int STAGES, int EPI, bool DIL>
+template <int BM, int BN, int WM, int WN, int STAGES, int EPI, bool SUB>
 __global__ void __launch_bounds__(64 * WM * WN, 2) igemm_kernel(IgemmArgs g) {
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int FP = BM / WM / 16;   // pixel fragments per wave
@@ -92,7 +100,19 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) igemm_kernel(IgemmArgs g) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int logical = xcd_remap(blockIdx.x, g.mtiles * g.ntiles);
+    int logical = xcd_remap(blockIdx.x, SUB ? g.cls_end[g.sub_s * g.sub_s - 1] : g.mtiles * g.ntiles);
+    // SUB: which parity class this block belongs to, and that class's pixel grid
+    int ph = 0, pw = 0, OHc = g.OH, OWc = g.OW, Mc = g.M;
+    if (SUB) {
+        int cls = 0;
+        while (logical >= g.cls_end[cls]) ++cls;
+        if (cls > 0) logical -= g.cls_end[cls - 1];
+        ph = g.cls_ph[cls];
+        pw = g.cls_pw[cls];
+        OHc = (g.OH - ph + g.sub_s - 1) / g.sub_s;
+        OWc = (g.OW - pw + g.sub_s - 1) / g.sub_s;
+        Mc = g.N * OHc * OWc;
+    }
     const int nt = logical % g.ntiles, mt = logical / g.ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
 
@@ -108,14 +128,13 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) igemm_kernel(IgemmArgs g) {
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
         const int m = m0 + (wave * RA + i) * 8 + (lane >> 3);
-        if (m < g.M) {
-            const int n = m / (g.OH * g.OW);
-            const int rem = m - n * (g.OH * g.OW);
-            const int oh = rem / g.OW, ow = rem - oh * g.OW;
-            bh[i] = oh * g.s_mul - g.pad;
-            bw[i] = ow * g.s_mul - g.pad;
-            if (DIL) rowbyte[i] = (unsigned)n * (unsigned)(g.H * g.W * g.PS * 2) + chunk * 16;
-            else rowbyte[i] = (unsigned)(((long long)(n * g.H + bh[i]) * g.W + bw[i]) * g.PS * 2) + chunk * 16;
+        if (m < Mc) {
+            const int n = m / (OHc * OWc);
+            const int rem = m - n * (OHc * OWc);
+            const int oh = rem / OWc, ow = rem - oh * OWc;
+            bh[i] = SUB ? oh : oh * g.s_mul - g.pad;   // SUB: class-grid coordinates; the tap supplies the shift
+            bw[i] = SUB ? ow : ow * g.s_mul - g.pad;
+            rowbyte[i] = (unsigned)(((long long)(n * g.H + bh[i]) * g.W + bw[i]) * g.PS * 2) + chunk * 16;
         } else {
             bh[i] = -(1 << 28);
             bw[i] = -(1 << 28);
@@ -126,38 +145,39 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) igemm_kernel(IgemmArgs g) {
     const unsigned wrow = (unsigned)(n0 + wave * RB * 8 + (lane >> 3)) * ktot * 2 + chunk * 16;
 
     const int cchunks = g.C / BK;
-    const int nit = g.KH * g.KW * cchunks;
+    // SUB: taps kh0, kh0 + s, ... (the ones with (ih - pad + kh) divisible by s for this class); source row =
+    // class row + (ph - pad + kh) / s, an exact division
+    const int kh0 = SUB ? ((g.pad - ph) % g.sub_s + g.sub_s) % g.sub_s : 0;
+    const int kw0 = SUB ? ((g.pad - pw) % g.sub_s + g.sub_s) % g.sub_s : 0;
+    const int kstep = SUB ? g.sub_s : 1;
+    const int nkh = kh0 < g.KH ? (g.KH - kh0 + kstep - 1) / kstep : 0;
+    const int nkw = kw0 < g.KW ? (g.KW - kw0 + kstep - 1) / kstep : 0;
+    const int nit = nkh * nkw * cchunks;
 
-    int kh = 0, kw = 0, cc = 0;   // position of the NEXT tile to stage
+    int kh = kh0, kw = kw0, cc = 0;   // position of the NEXT tile to stage
     typedef __attribute__((address_space(3))) void* lds_ptr;
 
     auto stage_tile = [&](int it, int buf) {
         unsigned char* base = smem + buf * TILE_BYTES;
-        const unsigned tapoff = (unsigned)(((kh * g.W + kw) * g.PS + cc * BK) * 2);
+        const int dh = SUB ? (ph - g.pad + kh) / g.sub_s : kh, dw = SUB ? (pw - g.pad + kw) / g.sub_s : kw;
+        const unsigned tapoff = (unsigned)(((dh * g.W + dw) * g.PS + cc * BK) * 2);
+        const unsigned wk = SUB ? (unsigned)(((kh * g.KW + kw) * g.C + cc * BK) * 2) : (unsigned)it * (BK * 2);
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            int sh = bh[i] + kh, sw = bw[i] + kw;
-            unsigned off;
-            bool ok;
-            if (DIL) {
-                ok = sh >= 0 && sw >= 0 && (sh % g.dil) == 0 && (sw % g.dil) == 0;
-                sh /= g.dil;
-                sw /= g.dil;
-                ok = ok && sh < g.H && sw < g.W;
-                off = rowbyte[i] + (unsigned)(((sh * g.W + sw) * g.PS + cc * BK) * 2);
-            } else {
-                ok = (unsigned)sh < (unsigned)g.H && (unsigned)sw < (unsigned)g.W;
-                off = rowbyte[i] + tapoff;
-            }
+            const int sh = bh[i] + dh, sw = bw[i] + dw;
+            const bool ok = (unsigned)sh < (unsigned)g.H && (unsigned)sw < (unsigned)g.W;
+            const unsigned off = rowbyte[i] + tapoff;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(base + (wave_u * RA + i) * 1024), 16, ok ? off : kOOB, 0, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < RB; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(base + BM * 128 + (wave_u * RB + i) * 1024), 16,
-                                                     wrow + (unsigned)(8 * i) * ktot * 2 + (unsigned)it * (BK * 2), 0, 0, 0);
+        for (int i = 0; i < RB; ++i) {
+            const unsigned off = wrow + (unsigned)(8 * i) * ktot * 2 + wk;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(base + BM * 128 + (wave_u * RB + i) * 1024), 16, off, 0, 0, 0);
+        }
         if (++cc == cchunks) {
             cc = 0;
-            if (++kw == g.KW) { kw = 0; ++kh; }
+            kw += kstep;
+            if (kw >= g.KW) { kw = kw0; kh += kstep; }
         }
     };
 
@@ -225,8 +245,14 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) igemm_kernel(IgemmArgs g) {
 #pragma unroll
     for (int p = 0; p < BM / RPP; ++p) {
         const int row = er + p * RPP;
-        const int m = m0 + row;
-        if (m >= g.M) continue;
+        int m = m0 + row;
+        if (m >= Mc) continue;
+        if (SUB) {   // class-grid pixel -> pixel of the full output
+            const int n = m / (OHc * OWc);
+            const int rem = m - n * (OHc * OWc);
+            const int oh = rem / OWc, ow = rem - oh * OWc;
+            m = (n * g.OH + oh * g.sub_s + ph) * g.OW + ow * g.sub_s + pw;
+        }
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(smem + row * EPI_STRIDE + ec * 4);
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(smem + row * EPI_STRIDE + ec * 4 + 16);
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
@@ -249,195 +275,6 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) igemm_kernel(IgemmArgs g) {
     }
 }
 
-// ---- high-occupancy variant: 32-deep K-steps, 34 KiB of LDS, four workgroups (16 waves) per CU ---------------
-// Same tile (BM x BN, 2x2 waves of 64x64) but the ring holds 64-byte rows (BK = 32 = one MFMA K-step), so a
-// workgroup needs 2 x 16 KiB instead of 2 x 32 KiB and the epilogue runs in two 64-row passes; with 115 VGPRs
-// four workgroups fit per CU and the hardware scheduler covers barrier and load waits with other workgroups.
-// LDS row = 4 chunks of 16 B; chunk c of row r sits in slot c ^ g((r>>2)&3), g = (0,3,2,1): with the
-// ds_read_b128 lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} every group then covers 16 distinct slots of
-// a 256-byte bank row (the plain XOR with (r>>2)&3 collides rows 0-3 with rows 4-7 of the neighbouring chunk).
-__device__ __forceinline__ unsigned swz32(int row, int chunk) {
-    return (unsigned)(row * 64 + ((chunk ^ ((0 - (row >> 2)) & 3)) << 4));
-}
-
-template <int BM, int BN, int NS, int EPI, bool DIL>
-__global__ void __launch_bounds__(kThreads, (NS <= 2 ? 4 : 2)) igemm32_kernel(IgemmArgs g) {
-    constexpr int WM = 2, WN = 2, KT = 32;
-    constexpr int FP = BM / WM / 16, FC = BN / WN / 16;
-    constexpr int RA = BM / 16 / 4, RB = BN / 16 / 4;   // LDS-DMA instructions per wave per tile (16 rows of 64 B each)
-    constexpr int TILE_BYTES = (BM + BN) * 64;
-    constexpr int EPI_STRIDE = BN * 4 + 16;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int logical = xcd_remap(blockIdx.x, g.mtiles * g.ntiles);
-    const int nt = logical % g.ntiles, mt = logical / g.ntiles;
-    const int m0 = mt * BM, n0 = nt * BN;
-
-    // lane l of a wave-instruction: row l>>2 of its 16-row group, LDS slot l&3 -> source chunk (l&3) ^ g(l>>4)
-    const int chunk = (lane & 3) ^ ((0 - (lane >> 4)) & 3);
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.x, g.xbytes), rw = make_rsrc(g.w, g.wbytes);
-    int bh[RA], bw[RA];
-    unsigned rowbyte[RA];
-#pragma unroll
-    for (int i = 0; i < RA; ++i) {
-        const int m = m0 + (wave * RA + i) * 16 + (lane >> 2);
-        if (m < g.M) {
-            const int n = m / (g.OH * g.OW);
-            const int rem = m - n * (g.OH * g.OW);
-            const int oh = rem / g.OW, ow = rem - oh * g.OW;
-            bh[i] = oh * g.s_mul - g.pad;
-            bw[i] = ow * g.s_mul - g.pad;
-            if (DIL) rowbyte[i] = (unsigned)n * (unsigned)(g.H * g.W * g.PS * 2) + chunk * 16;
-            else rowbyte[i] = (unsigned)(((long long)(n * g.H + bh[i]) * g.W + bw[i]) * g.PS * 2) + chunk * 16;
-        } else {
-            bh[i] = -(1 << 28);
-            bw[i] = -(1 << 28);
-            rowbyte[i] = 0;
-        }
-    }
-    const unsigned ktot = (unsigned)(g.KH * g.KW * g.C);
-    const unsigned wrow = (unsigned)(n0 + wave * RB * 16 + (lane >> 2)) * ktot * 2 + chunk * 16;
-    const int cchunks = g.C / KT;
-    const int nit = g.KH * g.KW * cchunks;
-    int kh = 0, kw = 0, cc = 0;
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-
-    // tiles past the end are still issued (all lanes out of range -> zeros into a ring slot nobody reads) so that
-    // the number of loads in flight, and with it the counted vmcnt below, is the same in every iteration
-    auto stage_tile = [&](int it, int buf) {
-        unsigned char* base = smem + buf * TILE_BYTES;
-        const bool live = it < nit;
-        const unsigned tapoff = (unsigned)(((kh * g.W + kw) * g.PS + cc * KT) * 2);
-#pragma unroll
-        for (int i = 0; i < RA; ++i) {
-            int sh = bh[i] + kh, sw = bw[i] + kw;
-            unsigned off;
-            bool ok;
-            if (DIL) {
-                ok = sh >= 0 && sw >= 0 && (sh % g.dil) == 0 && (sw % g.dil) == 0;
-                sh /= g.dil;
-                sw /= g.dil;
-                ok = ok && sh < g.H && sw < g.W;
-                off = rowbyte[i] + (unsigned)(((sh * g.W + sw) * g.PS + cc * KT) * 2);
-            } else {
-                ok = (unsigned)sh < (unsigned)g.H && (unsigned)sw < (unsigned)g.W;
-                off = rowbyte[i] + tapoff;
-            }
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(base + (wave_u * RA + i) * 1024), 16, (ok && live) ? off : kOOB, 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < RB; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(base + BM * 64 + (wave_u * RB + i) * 1024), 16,
-                                                     live ? wrow + (unsigned)(16 * i) * ktot * 2 + (unsigned)it * (KT * 2) : kOOB, 0, 0, 0);
-        if (++cc == cchunks) {
-            cc = 0;
-            if (++kw == g.KW) { kw = 0; ++kh; }
-        }
-    };
-
-    f32x4 acc[FC][FP];
-#pragma unroll
-    for (int a = 0; a < FC; ++a)
-#pragma unroll
-        for (int b = 0; b < FP; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-    for (int t = 0; t < NS - 1; ++t) stage_tile(t, t);
-    const int frow = lane & 15, fk = lane >> 4;
-    int cur = 0, nxt = NS - 1;
-    for (int it = 0; it < nit; ++it) {
-        wait_vmcnt<(NS - 2) * (RA + RB)>();   // tile `it` has landed; the NS-2 younger ones stay in flight
-        __syncthreads();                      // ... for every wave, and everyone is done reading slot `nxt`
-        stage_tile(it + NS - 1, nxt);
-        const unsigned char* pb = smem + cur * TILE_BYTES;
-        cur = cur + 1 == NS ? 0 : cur + 1;
-        nxt = nxt + 1 == NS ? 0 : nxt + 1;
-        const unsigned char* wb = pb + BM * 64;
-        bf16x8 wf[FC], pf[FP];
-#pragma unroll
-        for (int a = 0; a < FC; ++a) wf[a] = *reinterpret_cast<const bf16x8*>(wb + swz32(wn * (BN / WN) + a * 16 + frow, fk));
-#pragma unroll
-        for (int b = 0; b < FP; ++b) pf[b] = *reinterpret_cast<const bf16x8*>(pb + swz32(wm * (BM / WM) + b * 16 + frow, fk));
-#pragma unroll
-        for (int a = 0; a < FC; ++a)
-#pragma unroll
-            for (int b = 0; b < FP; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], pf[b], acc[a][b], 0, 0, 0);
-    }
-    wait_vmcnt<0>();
-    __syncthreads();
-
-    // ---- epilogue in WM passes of BM/WM rows (keeps LDS at 34 KiB) ------------------------------
-    constexpr int TPR = BN / 8;
-    constexpr int RPP = kThreads / TPR;
-    constexpr int PROWS = BM / WM;
-    const int ec = (tid % TPR) * 8, er = tid / TPR;
-    float bv[8];
-    if (EPI == EPI_BIAS_LEAKY) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) bv[j] = g.bias[n0 + ec + j];
-    }
-#pragma unroll
-    for (int pass = 0; pass < WM; ++pass) {
-        if (wm == pass) {
-#pragma unroll
-            for (int a = 0; a < FC; ++a)
-#pragma unroll
-                for (int b = 0; b < FP; ++b) {
-                    const int prow = b * 16 + frow;
-                    const int ch = wn * (BN / WN) + a * 16 + fk * 4;
-                    *reinterpret_cast<f32x4*>(smem + prow * EPI_STRIDE + ch * 4) = acc[a][b];
-                }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int p = 0; p < PROWS / RPP; ++p) {
-            const int row = er + p * RPP;
-            const int m = m0 + pass * PROWS + row;
-            if (m >= g.M) continue;
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(smem + row * EPI_STRIDE + ec * 4);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(smem + row * EPI_STRIDE + ec * 4 + 16);
-            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            const long long o = (long long)m * g.NOUT + n0 + ec;
-            if (EPI == EPI_BIAS_LEAKY) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float t = v[j] + bv[j];
-                    v[j] = t > 0.0f ? t : t * g.slope;
-                }
-            } else if (EPI == EPI_MASK) {
-                const bf16x8 av = *reinterpret_cast<const bf16x8*>(g.act + o);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = (float)av[j] > 0.0f ? v[j] : v[j] * g.slope;
-            }
-            bf16x8 ov;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) ov[j] = (bf16_t)v[j];
-            *reinterpret_cast<bf16x8*>(g.out + o) = ov;
-        }
-        __syncthreads();
-    }
-}
-
-template <int BM, int BN, int NS, int EPI, bool DIL>
-int launch_igemm32(IgemmArgs& g, hipStream_t s, const char* name) {
-    g.mtiles = (int)yfs_cdiv(g.M, BM);
-    g.ntiles = g.NOUT / BN;
-    size_t stage = NS * (size_t)(BM + BN) * 64, epi = (size_t)(BM / 2) * (BN * 4 + 16);
-    const size_t lds = stage > epi ? stage : epi;
-    auto kern = igemm32_kernel<BM, BN, NS, EPI, DIL>;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        YFS_REQUIRE(e == hipSuccess, YFS_ERR_LAUNCH, "%s: cannot reserve %zu bytes of LDS", name, lds);
-    }
-    kern<<<dim3((unsigned)(g.mtiles * g.ntiles)), dim3(kThreads), lds, s>>>(g);
-    YFS_CHECK_LAUNCH(name);
-    return YFS_OK;
-}
-
 template <int BM, int BN, int STAGES>
 constexpr size_t igemm_lds_bytes() {
     size_t stage = (size_t)STAGES * (BM + BN) * 128;
@@ -445,34 +282,55 @@ constexpr size_t igemm_lds_bytes() {
     return stage > epi ? stage : epi;
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int EPI, bool DIL>
+template <int BM, int BN, int WM, int WN, int STAGES, int EPI, bool SUB>
 int launch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
     g.mtiles = (int)yfs_cdiv(g.M, BM);
     g.ntiles = g.NOUT / BN;
+    long long nblk = (long long)g.mtiles * g.ntiles;
+    if (SUB) {
+        // parity classes ordered by tap count, heaviest first, so the long blocks are not left for the tail
+        const int sb = g.sub_s;
+        YFS_REQUIRE(sb == 2, YFS_ERR_UNSUPPORTED, "%s: strided dgrad supports stride 2 only (got %d)", name, sb);
+        int order[4] = {0, 1, 2, 3}, taps[4];
+        for (int c = 0; c < 4; ++c) {
+            const int ph = c / sb, pw = c % sb;
+            const int kh0 = ((g.pad - ph) % sb + sb) % sb, kw0 = ((g.pad - pw) % sb + sb) % sb;
+            taps[c] = (kh0 < g.KH ? (g.KH - kh0 + sb - 1) / sb : 0) * (kw0 < g.KW ? (g.KW - kw0 + sb - 1) / sb : 0);
+        }
+        std::stable_sort(order, order + 4, [&](int a, int b) { return taps[a] > taps[b]; });
+        nblk = 0;
+        for (int k = 0; k < 4; ++k) {
+            const int ph = order[k] / sb, pw = order[k] % sb;
+            const long long Mc = (long long)g.N * ((g.OH - ph + sb - 1) / sb) * ((g.OW - pw + sb - 1) / sb);
+            nblk += yfs_cdiv(Mc, BM) * g.ntiles;   // an empty class (OH or OW == 1) contributes no blocks
+            g.cls_ph[k] = ph; g.cls_pw[k] = pw; g.cls_end[k] = (int)nblk;
+        }
+    }
     const size_t lds = igemm_lds_bytes<BM, BN, STAGES>();
-    auto kern = igemm_kernel<BM, BN, WM, WN, STAGES, EPI, DIL>;
+    auto kern = igemm_kernel<BM, BN, WM, WN, STAGES, EPI, SUB>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         YFS_REQUIRE(e == hipSuccess, YFS_ERR_LAUNCH, "%s: cannot reserve %zu bytes of LDS", name, lds);
     }
-    kern<<<dim3((unsigned)(g.mtiles * g.ntiles)), dim3(64 * WM * WN), lds, s>>>(g);
+    kern<<<dim3((unsigned)nblk), dim3(64 * WM * WN), lds, s>>>(g);
     YFS_CHECK_LAUNCH(name);
     return YFS_OK;
 }
 
 // Tile choice (measured on MI355X, batch 64, tools/conv_bench.py): 128x128 / 4 waves / 2-stage 64-deep ring at two
-// workgroups per CU is the fastest on every backbone layer (L7 1015, L18 1097 TFLOP/s); 256x128 / 8 waves / 3 stages
-// (one per CU) reaches 875-990 and the 32-deep four-per-CU variant 790-880, so neither is selected by default.
-// 128x64 serves the 192-channel outputs.  YFS_IGEMM_TILE=256|32 selects the alternatives for benchmarking.
-template <int EPI, bool DIL>
+// workgroups per CU is the fastest on every backbone layer (L7 ~1000, L18 ~1070 TFLOP/s).  Tried and rejected:
+// 256x128 / 8 waves / 3 stages at one workgroup per CU (875-990), 32-deep rings at four workgroups per CU
+// (790-880), 32-deep 4/5-stage rings (780-870), 256x128 / 4 waves / 32-deep (810-980).  Ablations show why the
+// kernel sits at ~40 % of the MFMA peak: with the global->LDS staging removed the same loop runs at 1340-1560
+// TFLOP/s, with staging that fetches nothing (all lanes out of range) at 1050-1240: at 128x128 the tile stream
+// needs ~15.7 TB/s from the XCD L2s, close to what L2 -> LDS delivers chip-wide (17-19 TB/s).
+// 128x64 serves the 192-channel outputs.  YFS_IGEMM_TILE=256 selects the 256x128 variant for benchmarking.
+template <int EPI, bool SUB>
 int dispatch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
-    if (g.NOUT % 128 != 0) return launch_igemm<128, 64, 2, 2, 2, EPI, DIL>(g, s, name);
+    if (g.NOUT % 128 != 0) return launch_igemm<128, 64, 2, 2, 2, EPI, SUB>(g, s, name);
     static const int force = [] { const char* e = getenv("YFS_IGEMM_TILE"); return e ? atoi(e) : 0; }();
-    if (force == 32) return launch_igemm32<128, 128, 2, EPI, DIL>(g, s, name);
-    if (force == 324) return launch_igemm32<128, 128, 4, EPI, DIL>(g, s, name);
-    if (force == 325) return launch_igemm32<128, 128, 5, EPI, DIL>(g, s, name);
-    if (force == 256) return launch_igemm<256, 128, 4, 2, 3, EPI, DIL>(g, s, name);
-    return launch_igemm<128, 128, 2, 2, 2, EPI, DIL>(g, s, name);
+    if (force == 256) return launch_igemm<256, 128, 4, 2, 3, EPI, SUB>(g, s, name);
+    return launch_igemm<128, 128, 2, 2, 2, EPI, SUB>(g, s, name);
 }
 
 int check_conv_shape(const char* fn, int64_t N, int H, int W, int Cin, int Cout, int K, int stride) {
@@ -500,7 +358,7 @@ YFS_API int yfs_conv2d_fwd_bf16(const void* x, const void* w, const float* bias,
     g.x = (const bf16_t*)x; g.w = (const bf16_t*)w; g.bias = bias; g.out = (bf16_t*)y;
     g.N = (int)N; g.H = H; g.W = W; g.C = Cin;
     g.OH = (H + 2 * pad - K) / stride + 1; g.OW = (W + 2 * pad - K) / stride + 1; g.NOUT = Cout;
-    g.KH = g.KW = K; g.PS = Cin; g.s_mul = stride; g.pad = pad; g.dil = 1; g.slope = slope;
+    g.KH = g.KW = K; g.PS = Cin; g.s_mul = stride; g.pad = pad; g.slope = slope;
     g.M = (int)(N * g.OH * g.OW);
     g.xbytes = (unsigned)(N * H * W * Cin * 2); g.wbytes = (unsigned)((int64_t)Cout * K * K * Cin * 2);
     return dispatch_igemm<EPI_BIAS_LEAKY, false>(g, (hipStream_t)stream, "yfs_conv2d_fwd_bf16");
@@ -517,7 +375,7 @@ YFS_API int yfs_conv2d_dgrad_bf16(const void* dz, const void* wt, const void* x_
     g.N = (int)N;
     g.H = (H + 2 * pad - K) / stride + 1; g.W = (W + 2 * pad - K) / stride + 1; g.C = Cout;   // gathered tensor = dz
     g.OH = H; g.OW = W; g.NOUT = Cin;
-    g.KH = g.KW = K; g.PS = Cout; g.s_mul = 1; g.pad = K - 1 - pad; g.dil = stride; g.slope = slope;
+    g.KH = g.KW = K; g.PS = Cout; g.s_mul = 1; g.pad = K - 1 - pad; g.sub_s = stride; g.slope = slope;
     g.M = (int)(N * H * W);
     g.xbytes = (unsigned)(N * g.H * g.W * Cout * 2); g.wbytes = (unsigned)((int64_t)Cout * K * K * Cin * 2);
     hipStream_t s = (hipStream_t)stream;
@@ -998,7 +856,7 @@ YFS_API int yfs_conv2d_stem_fwd_bf16(const void* xs, const void* w2, const float
     IgemmArgs g = {};
     g.x = (const bf16_t*)xs; g.w = (const bf16_t*)w2; g.bias = bias; g.out = (bf16_t*)y;
     g.N = (int)N; g.H = Hs; g.W = Ws; g.C = 64; g.PS = kStemC; g.OH = OH; g.OW = OW; g.NOUT = Cout;
-    g.KH = kStemKH; g.KW = 1; g.s_mul = 1; g.pad = 0; g.dil = 1; g.slope = slope;
+    g.KH = kStemKH; g.KW = 1; g.s_mul = 1; g.pad = 0; g.slope = slope;
     g.M = (int)(N * OH * OW);
     g.xbytes = (unsigned)(N * Hs * Ws * kStemC * 2); g.wbytes = (unsigned)((int64_t)Cout * kStemKH * 64 * 2);
     return dispatch_igemm<EPI_BIAS_LEAKY, false>(g, (hipStream_t)stream, "yfs_conv2d_stem_fwd_bf16");
