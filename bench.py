@@ -195,7 +195,7 @@ def main():
     model.train()                                    # Dropout(0.2) active, as in the reference's train loop
     comm = dp.GradComm(world, compress_bf16=args.compress_bf16) if world > 1 else None
     opt = yt.FlatSGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=5e-4, max_norm=1.0, comm=comm)
-    dp.broadcast_parameters(opt.flat_p)
+    dp.broadcast_parameters(opt)
     crit = y.YoloV1Loss(7, 2, 20)
     g = torch.Generator().manual_seed(rank)
     x = torch.rand(args.batch, 3, 448, 448, generator=g).to(device).to(torch.bfloat16).contiguous(

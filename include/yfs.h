@@ -159,11 +159,14 @@ int yfs_maxpool2_bwd_bf16(const void *x, const void *dy, void *dx, int64_t N, in
  * fp32 arenas (all parameters / gradients / momentum buffers live in one allocation each).
  * yfs_sumsq_f32: sumsq_out[0] = sum g^2 (deterministic two-stage reduction).
  * yfs_sgd_step_f32: clip = min(1, max_norm / (sqrt(*sumsq) + 1e-6)) (no clipping when sumsq == NULL or
- * max_norm <= 0); d = clip*g + wd*p; buf = first_step ? d : momentum*buf + d; p -= lr*buf. */
+ * max_norm <= 0); d = clip*g + wd*p; buf = first_step ? d : momentum*buf + d; p -= lr*buf.  p_bf16 (may be
+ * NULL): bf16 [n] shadow of the updated p, written in the same pass (the next step's conv / linear kernels
+ * read it instead of casting the fp32 master weights again; reference counterpart: autocast's per-step
+ * weight casts, yolo_toy_regressor_torch.py:323). */
 size_t yfs_sumsq_workspace_bytes(int64_t n);
 int yfs_sumsq_f32(const float *g, int64_t n, float *sumsq_out, void *workspace, size_t workspace_bytes, void *stream);
 int yfs_sgd_step_f32(float *p, const float *g, float *buf, int64_t n, const float *sumsq, float max_norm,
-                     float lr, float momentum, float weight_decay, int first_step, void *stream);
+                     float lr, float momentum, float weight_decay, int first_step, void *p_bf16, void *stream);
 
 #ifdef __cplusplus
 }

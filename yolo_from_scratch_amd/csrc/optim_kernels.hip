@@ -36,7 +36,8 @@ __global__ void __launch_bounds__(kThreads) sumsq_finalize_kernel(const float* _
 
 __global__ void __launch_bounds__(kThreads) sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
                                                        long long n, const float* __restrict__ sumsq, float max_norm, float lr,
-                                                       float momentum, float wd, int first_step) {
+                                                       float momentum, float wd, int first_step,
+                                                       __bf16* __restrict__ p16) {
     float coef = 1.0f;
     if (sumsq && max_norm > 0.0f) {
         const float c = max_norm / (sqrtf(sumsq[0]) + 1e-6f);   // clip_grad_norm_: clamp(max_norm / (norm + 1e-6), max=1)
@@ -59,13 +60,21 @@ __global__ void __launch_bounds__(kThreads) sgd_kernel(float* __restrict__ p, co
         pv.x -= lr * bv.x; pv.y -= lr * bv.y; pv.z -= lr * bv.z; pv.w -= lr * bv.w;
         b4[i] = bv;
         p4[i] = pv;
+        if (p16) {   // bf16 shadow of the updated parameters: what the conv / linear kernels read next step
+            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+            bf16x4_t o;
+            o[0] = (__bf16)pv.x; o[1] = (__bf16)pv.y; o[2] = (__bf16)pv.z; o[3] = (__bf16)pv.w;
+            reinterpret_cast<bf16x4_t*>(p16)[i] = o;
+        }
     }
     if (blockIdx.x == 0) {
         for (long long i = (n4 << 2) + threadIdx.x; i < n; i += kThreads) {
             const float d = g[i] * coef + wd * p[i];
             const float b = first_step ? d : momentum * buf[i] + d;
             buf[i] = b;
-            p[i] -= lr * b;
+            const float pn = p[i] - lr * b;
+            p[i] = pn;
+            if (p16) p16[i] = (__bf16)pn;
         }
     }
 }
@@ -93,12 +102,12 @@ YFS_API int yfs_sumsq_f32(const float* g, int64_t n, float* sumsq_out, void* wor
 }
 
 YFS_API int yfs_sgd_step_f32(float* p, const float* g, float* buf, int64_t n, const float* sumsq, float max_norm, float lr,
-                             float momentum, float weight_decay, int first_step, void* stream) {
+                             float momentum, float weight_decay, int first_step, void* p_bf16, void* stream) {
     YFS_REQUIRE(p && g && buf && n > 0, YFS_ERR_INVALID_ARG, "yfs_sgd_step_f32: null pointer or n <= 0");
     YFS_REQUIRE(((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(buf)) & 15) == 0,
                 YFS_ERR_INVALID_ARG, "yfs_sgd_step_f32: p, g and buf must be 16-byte aligned");
     sgd_kernel<<<dim3(nblocks(n)), dim3(kThreads), 0, (hipStream_t)stream>>>(p, g, buf, n, sumsq, max_norm, lr, momentum,
-                                                                          weight_decay, first_step);
+                                                                          weight_decay, first_step, (__bf16*)p_bf16);
     YFS_CHECK_LAUNCH("sgd_kernel");
     return YFS_OK;
 }

@@ -113,6 +113,12 @@ class GradComm:
 
 
 def broadcast_parameters(flat_p, src=0, group=None):
-    """Identical initial weights on every rank."""
+    """Identical initial weights on every rank.  ``flat_p`` is the optimiser's flat
+    fp32 arena, or the FlatSGD itself (then its bf16 shadow is refreshed as well)."""
+    opt = None
+    if hasattr(flat_p, "flat_p"):
+        opt, flat_p = flat_p, flat_p.flat_p
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.broadcast(flat_p, src=src, group=group)
+        if opt is not None:
+            opt.sync_shadow()

@@ -54,7 +54,12 @@ class _ConvPlan:
             self.w16 = co.stem_weight(weight)
             self.wt16 = None
         else:
-            self.w16, self.wt16 = co.weight_prep(weight, want_wt16=need_wt)
+            from .train import bf16_shadow
+            self.w16 = bf16_shadow(weight)      # written by the optimiser step; None without FlatSGD
+            if self.w16 is None:
+                self.w16, self.wt16 = co.weight_prep(weight, want_wt16=need_wt)
+            else:
+                self.wt16 = co.weight_prep(weight, want_w16=False)[1] if need_wt else None
         self.bias = bias.detach().float().contiguous()
 
     def forward(self, x):
@@ -268,8 +273,11 @@ class _LinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias):
+        from .train import bf16_shadow
         x16 = x.to(torch.bfloat16)
-        w16 = weight.detach().to(torch.bfloat16)
+        w16 = bf16_shadow(weight)
+        if w16 is None:
+            w16 = weight.detach().to(torch.bfloat16)
         ctx.save_for_backward(x16, w16)
         ctx.wb, ctx.in_dtype = (weight, bias), x.dtype
         return torch.addmm(bias.detach().to(torch.bfloat16), x16, w16.t())
@@ -281,12 +289,15 @@ class _LinearFn(torch.autograd.Function):
         weight, bias = ctx.wb
         dy16 = dy.to(torch.bfloat16).contiguous()
         dx = torch.mm(dy16, w16).to(ctx.in_dtype) if ctx.needs_input_grad[0] else None
-        dw16 = torch.mm(dy16.t(), x16)
 
-        def put_w(sink, acc):
-            if sink is None:
-                return dw16.float()
-            sink.add_(dw16) if acc else sink.copy_(dw16)
+        def put_w(sink, acc):     # bf16 operands, fp32 result straight into the gradient arena (no bf16 round trip)
+            if sink is None or acc:
+                dw = torch.mm(dy16.t(), x16, out_dtype=torch.float32)
+                if sink is None:
+                    return dw
+                sink.add_(dw)
+            else:
+                torch.mm(dy16.t(), x16, out_dtype=torch.float32, out=sink)
 
         def put_b(sink, acc):
             db = dy16.float().sum(0)

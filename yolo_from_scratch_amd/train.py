@@ -61,6 +61,7 @@ class FlatSGD(torch.optim.Optimizer):
         self.flat_p = torch.zeros(total, device=dev, dtype=torch.float32)
         self.flat_g = torch.zeros(total, device=dev, dtype=torch.float32)
         self.flat_m = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.flat_p16 = torch.zeros(total, device=dev, dtype=torch.bfloat16)   # bf16 shadow, rewritten by every step
         self.offsets = []
         off = 0
         for p, sz in zip(params, sizes):
@@ -74,9 +75,11 @@ class FlatSGD(torch.optim.Optimizer):
             p.grad = gv
             p._yfs_grad_sink = gv
             p._yfs_grad_fresh = bool(getattr(p, "_yfs_sink_capable", False))
+            p._yfs_bf16 = torch.as_strided(self.flat_p16, p.shape, p.stride(), off)
             self.offsets.append((off, n))
             off += sz
         self.total = total
+        self.sync_shadow()
         self.max_norm = max_norm
         self.comm = comm
         self._params = params
@@ -117,6 +120,19 @@ class FlatSGD(torch.optim.Optimizer):
                     grad_ready(p)       # gradient came through plain autograd: complete by now
 
     @torch.no_grad()
+    def sync_shadow(self):
+        """Recompute the bf16 shadow from the fp32 master weights.  Done at construction; in-place writes to a
+        parameter (load_state_dict, p.copy_) are noticed through the tensor version and refreshed lazily by
+        bf16_shadow(); call this after writing through ``p.data`` / the flat arena, which no version tracks."""
+        self.flat_p16.copy_(self.flat_p)
+        for p in self._all_params():
+            p._yfs_bf16_ver = p._version
+
+    def _all_params(self):
+        for group in self.param_groups:
+            yield from group["params"]
+
+    @torch.no_grad()
     def grad_norm(self):
         L.check(L.lib().yfs_sumsq_f32(L.ptr(self.flat_g), L.i64(self.total), L.ptr(self._sumsq), L.ptr(self._ws),
                                       L.c_size(self._ws_bytes), L.stream()), "yfs_sumsq_f32")
@@ -136,8 +152,21 @@ class FlatSGD(torch.optim.Optimizer):
         L.check(L.lib().yfs_sgd_step_f32(L.ptr(self.flat_p), L.ptr(self.flat_g), L.ptr(self.flat_m), L.i64(self.total),
                                          L.ptr(sumsq), L.c_float(max_norm or 0.0), L.c_float(g["lr"]),
                                          L.c_float(g["momentum"]), L.c_float(g["weight_decay"]),
-                                         L.c_int(1 if self._first else 0), L.stream()), "yfs_sgd_step_f32")
+                                         L.c_int(1 if self._first else 0), L.ptr(self.flat_p16), L.stream()),
+                "yfs_sgd_step_f32")
         self._first = False
+
+
+def bf16_shadow(param):
+    """bf16 copy of ``param`` kept current by FlatSGD.step (None when the parameter is not in a FlatSGD)."""
+    sh = getattr(param, "_yfs_bf16", None)
+    if sh is None:
+        return None
+    if param._version != param._yfs_bf16_ver:      # written in place since the last step (e.g. load_state_dict)
+        with torch.no_grad():
+            sh.copy_(param.detach())
+        param._yfs_bf16_ver = param._version
+    return sh
 
 
 def write_grad(param, value_fn):
