@@ -81,6 +81,23 @@ __device__ __forceinline__ unsigned swz(int row, int chunk) { return (unsigned)(
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// Epilogue row slabs: one pass when the fp32 tile (BM rows of BN*4+16 bytes) fits in ~72 KiB (the 128-wide tiles),
+// else the smallest power-of-two split whose slab fits inside the operand ring.
+template <int BM, int BN, int STAGES>
+constexpr int igemm_epi_passes() {
+    const size_t ring = (size_t)STAGES * (BM + BN) * 128, row = (size_t)BN * 4 + 16;
+    if ((size_t)BM * row <= 72 * 1024) return 1;
+    int p = 2;
+    while ((size_t)(BM / p) * row > ring) p *= 2;
+    return p;
+}
+template <int BM, int BN, int STAGES>
+constexpr size_t igemm_lds_bytes() {
+    const size_t ring = (size_t)STAGES * (BM + BN) * 128;
+    const size_t epi = (size_t)(BM / igemm_epi_passes<BM, BN, STAGES>()) * (BN * 4 + 16);
+    return ring > epi ? ring : epi;
+}
+
 // BM pixels x BN channels per workgroup, WM x WN waves (wave tile BM/WM x BN/WN), STAGES-deep LDS ring.
 //   <128,128,2,2,2>: 4 waves, 64 KiB ring, 2 workgroups per CU (the other workgroup covers the barrier waits)
 //   <256,128,4,2,3>: 8 waves, 144 KiB ring, 1 workgroup per CU: 1/3 less L2->LDS traffic per FLOP (the 128x128
@@ -224,18 +241,13 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) igemm_kernel(IgemmArgs g) {
     __syncthreads();   // all waves done with the ring before the epilogue reuses it
 
     // ---- epilogue: fp32 tile through LDS, then coalesced 16 B stores ---------------------------
-    // acc[a][b][r] = out[pixel = wm*BM/2 + b*16 + (lane&15)][chan = wn*BN/2 + a*16 + (lane>>4)*4 + r]
-#pragma unroll
-    for (int a = 0; a < FC; ++a)
-#pragma unroll
-        for (int b = 0; b < FP; ++b) {
-            const int prow = wm * (BM / WM) + b * 16 + frow;
-            const int ch = wn * (BN / WN) + a * 16 + fk * 4;
-            *reinterpret_cast<f32x4*>(smem + prow * EPI_STRIDE + ch * 4) = acc[a][b];
-        }
-    __syncthreads();
+    // acc[a][b][r] = out[pixel = wm*BM/WM + b*16 + (lane&15)][chan = wn*BN/WN + a*16 + (lane>>4)*4 + r]
+    // Large tiles go through the LDS in EPASS row slabs of PR rows so that the staging fits in the ring.
+    constexpr int EPASS = igemm_epi_passes<BM, BN, STAGES>();
+    constexpr int PR = BM / EPASS;
     constexpr int TPR = BN / 8;            // threads per output row (8 channels each)
-    constexpr int RPP = NT / TPR;          // rows per pass
+    constexpr int RPP = NT / TPR;          // rows per sweep of the whole workgroup
+    static_assert(PR % 16 == 0 && PR % RPP == 0, "epilogue slab must hold whole fragments and whole sweeps");
     const int ec = (tid % TPR) * 8, er = tid / TPR;
     float bv[8];
     if (EPI == EPI_BIAS_LEAKY) {
@@ -243,43 +255,50 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) igemm_kernel(IgemmArgs g) {
         for (int j = 0; j < 8; ++j) bv[j] = g.bias[n0 + ec + j];
     }
 #pragma unroll
-    for (int p = 0; p < BM / RPP; ++p) {
-        const int row = er + p * RPP;
-        int m = m0 + row;
-        if (m >= Mc) continue;
-        if (SUB) {   // class-grid pixel -> pixel of the full output
-            const int n = m / (OHc * OWc);
-            const int rem = m - n * (OHc * OWc);
-            const int oh = rem / OWc, ow = rem - oh * OWc;
-            m = (n * g.OH + oh * g.sub_s + ph) * g.OW + ow * g.sub_s + pw;
-        }
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(smem + row * EPI_STRIDE + ec * 4);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(smem + row * EPI_STRIDE + ec * 4 + 16);
-        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        const long long o = (long long)m * g.NOUT + n0 + ec;
-        if (EPI == EPI_BIAS_LEAKY) {
+    for (int pass = 0; pass < EPASS; ++pass) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float t = v[j] + bv[j];
-                v[j] = t > 0.0f ? t : t * g.slope;
+        for (int a = 0; a < FC; ++a)
+#pragma unroll
+            for (int b = 0; b < FP; ++b) {
+                const int prow = wm * (BM / WM) + b * 16;
+                if (EPASS > 1 && prow / PR != pass) continue;
+                const int ch = wn * (BN / WN) + a * 16 + fk * 4;
+                *reinterpret_cast<f32x4*>(smem + (prow - pass * PR + frow) * EPI_STRIDE + ch * 4) = acc[a][b];
             }
-        } else if (EPI == EPI_MASK) {
-            const bf16x8 av = *reinterpret_cast<const bf16x8*>(g.act + o);
+        __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (float)av[j] > 0.0f ? v[j] : v[j] * g.slope;
+        for (int p = 0; p < PR / RPP; ++p) {
+            const int row = er + p * RPP;
+            int m = m0 + pass * PR + row;
+            if (m >= Mc) continue;
+            if (SUB) {   // class-grid pixel -> pixel of the full output
+                const int n = m / (OHc * OWc);
+                const int rem = m - n * (OHc * OWc);
+                const int oh = rem / OWc, ow = rem - oh * OWc;
+                m = (n * g.OH + oh * g.sub_s + ph) * g.OW + ow * g.sub_s + pw;
+            }
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(smem + row * EPI_STRIDE + ec * 4);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(smem + row * EPI_STRIDE + ec * 4 + 16);
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            const long long o = (long long)m * g.NOUT + n0 + ec;
+            if (EPI == EPI_BIAS_LEAKY) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float t = v[j] + bv[j];
+                    v[j] = t > 0.0f ? t : t * g.slope;
+                }
+            } else if (EPI == EPI_MASK) {
+                const bf16x8 av = *reinterpret_cast<const bf16x8*>(g.act + o);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (float)av[j] > 0.0f ? v[j] : v[j] * g.slope;
+            }
+            bf16x8 ov;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ov[j] = (bf16_t)v[j];
+            *reinterpret_cast<bf16x8*>(g.out + o) = ov;
         }
-        bf16x8 ov;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ov[j] = (bf16_t)v[j];
-        *reinterpret_cast<bf16x8*>(g.out + o) = ov;
+        if (pass + 1 < EPASS) __syncthreads();
     }
-}
-
-template <int BM, int BN, int STAGES>
-constexpr size_t igemm_lds_bytes() {
-    size_t stage = (size_t)STAGES * (BM + BN) * 128;
-    size_t epi = (size_t)BM * (BN * 4 + 16);
-    return stage > epi ? stage : epi;
 }
 
 template <int BM, int BN, int WM, int WN, int STAGES, int EPI, bool SUB>
@@ -317,19 +336,31 @@ int launch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
     return YFS_OK;
 }
 
-// Tile choice (measured on MI355X, batch 64, tools/conv_bench.py): 128x128 / 4 waves / 2-stage 64-deep ring at two
-// workgroups per CU is the fastest on every backbone layer (L7 ~1000, L18 ~1070 TFLOP/s).  Tried and rejected:
-// 256x128 / 8 waves / 3 stages at one workgroup per CU (875-990), 32-deep rings at four workgroups per CU
-// (790-880), 32-deep 4/5-stage rings (780-870), 256x128 / 4 waves / 32-deep (810-980).  Ablations show why the
-// kernel sits at ~40 % of the MFMA peak: with the global->LDS staging removed the same loop runs at 1340-1560
-// TFLOP/s, with staging that fetches nothing (all lanes out of range) at 1050-1240: at 128x128 the tile stream
-// needs ~15.7 TB/s from the XCD L2s, close to what L2 -> LDS delivers chip-wide (17-19 TB/s).
-// 128x64 serves the 192-channel outputs.  YFS_IGEMM_TILE=256 selects the 256x128 variant for benchmarking.
+// Tile choice (measured on MI355X, batch 64, tools/conv_bench.py).  Default: 128x128 / 4 waves / 2-stage 64-deep
+// ring at two workgroups per CU (L7 ~1000, L18 ~1070 TFLOP/s).  Ablations show why it sits at ~40 % of the MFMA
+// peak: with the global->LDS staging removed the same loop runs at 1340-1560 TFLOP/s, with staging that fetches
+// nothing (all lanes out of range) at 1050-1240: a 128x128 tile streams 32 KiB per 2.1 MFLOP, ~31 B/clk/CU at
+// this rate, which is what the vector-memory -> LDS path sustains per CU (MI355X_MICROARCH.md: 66-73 GB/s per CU).
+// 256x256 / 8 waves / one workgroup per CU halves the bytes per FLOP and reaches 1090-1130 TFLOP/s where its tile
+// count quantises well on 256 CUs (196, 392, 3136 tiles), but loses when it does not (98, 784) or when K is short
+// (four-pass epilogue); it is chosen by the round-count model below.  Tried and rejected: 256x128 / 8 waves /
+// 3 stages (875-990), 32-deep rings at four workgroups per CU (790-880), 32-deep 4/5-stage rings (780-870),
+// 256x128 / 4 waves / 32-deep (810-980), issuing the loads between the MFMAs instead of in a burst (-6 %).
+// 128x64 serves the 192-channel outputs.  YFS_IGEMM_TILE=128|256|2562 forces a variant for benchmarking.
 template <int EPI, bool SUB>
 int dispatch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
     if (g.NOUT % 128 != 0) return launch_igemm<128, 64, 2, 2, 2, EPI, SUB>(g, s, name);
     static const int force = [] { const char* e = getenv("YFS_IGEMM_TILE"); return e ? atoi(e) : 0; }();
     if (force == 256) return launch_igemm<256, 128, 4, 2, 3, EPI, SUB>(g, s, name);
+    bool big = force == 2562;
+    if (force == 0 && !SUB) {
+        // rounds x time per round: 128x128 runs 512 tiles per round (2 per CU) in 2u, 256x256 runs 256 tiles per
+        // round in 4u / 1.18 (its measured per-CU advantage); take the big tile when that wins by >= 10 %.
+        const long long t128 = yfs_cdiv(g.M, 128) * (g.NOUT / 128), t256 = yfs_cdiv(g.M, 256) * yfs_cdiv(g.NOUT, 256);
+        const double c128 = (double)yfs_cdiv(t128, 512) * 2.0, c256 = (double)yfs_cdiv(t256, 256) * (4.0 / 1.18);
+        big = c256 < 0.9 * c128 && g.KH * g.KW * g.C >= 2304;
+    }
+    if (big && g.NOUT % 256 == 0) return launch_igemm<256, 256, 2, 4, 2, EPI, SUB>(g, s, name);
     return launch_igemm<128, 128, 2, 2, 2, EPI, SUB>(g, s, name);
 }
 
