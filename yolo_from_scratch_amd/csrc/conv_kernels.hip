@@ -651,17 +651,43 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
     }
 }
 
-// dw[i] = (accumulate ? dw[i] : 0) + sum_s partial[s][i], fixed order over s.
+// dw[i] = (accumulate ? dw[i] : 0) + sum_s partial[s][i].  G groups of threads share one float4 column: group r
+// sums slabs r, r+G, ... and the G sums are combined through LDS in fixed order (deterministic).  Small outputs
+// with many slabs (1x1 layers: 32K floats x 224 slabs) would otherwise run on a few dozen serial threads.
+template <int G>
 __global__ void __launch_bounds__(kThreads) splitk_reduce_kernel(const float4* __restrict__ partial, int splits,
                                                                  long long n4, float4* __restrict__ dw,
                                                                  int accumulate) {
-    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n4; i += (long long)gridDim.x * kThreads) {
-        float4 s = accumulate ? dw[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k = 0; k < splits; ++k) {
-            const float4 v = partial[(long long)k * n4 + i];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    constexpr int COLS = kThreads / G;
+    __shared__ float4 red[G][COLS];
+    const int cl = threadIdx.x % COLS, r = threadIdx.x / COLS;
+    for (long long i0 = (long long)blockIdx.x * COLS; i0 < n4; i0 += (long long)gridDim.x * COLS) {
+        const long long i = i0 + cl;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n4)
+            for (int k = r; k < splits; k += G) {
+                const float4 v = partial[(long long)k * n4 + i];
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        if (G > 1) {
+            red[r][cl] = s;
+            __syncthreads();
+            if (r == 0) {
+#pragma unroll
+                for (int k = 1; k < G; ++k) {
+                    const float4 v = red[k][cl];
+                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                }
+            }
+            __syncthreads();
         }
-        dw[i] = s;
+        if (r == 0 && i < n4) {
+            if (accumulate) {
+                const float4 o = dw[i];
+                s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+            }
+            dw[i] = s;
+        }
     }
 }
 
@@ -787,10 +813,14 @@ int wgrad_common(const char* fn, const void* x, const void* dz, float* dw, float
     else rc = launch_wgrad<64, 64>(g, p, s);
     if (rc) return rc;
     const long long n4 = (long long)Cout * taps * Cin / 4;
-    long long rblk = yfs_cdiv(n4, kThreads);
-    if (rblk > 2048) rblk = 2048;
-    splitk_reduce_kernel<<<dim3((unsigned)rblk), dim3(kThreads), 0, s>>>((const float4*)workspace, p.splits, n4, (float4*)dw,
-                                                                      accumulate);
+    // enough thread groups per column that the reduce has >= ~64K threads in flight even for small outputs
+    const int G = (p.splits >= 32 && n4 * 4 < 65536 * 4) ? 16 : ((p.splits >= 8 && n4 < 65536 * 4) ? 4 : 1);
+    long long rblk = yfs_cdiv(n4, kThreads / G);
+    if (rblk > 4096) rblk = 4096;
+    const float4* part4 = (const float4*)workspace;
+    if (G == 16) splitk_reduce_kernel<16><<<dim3((unsigned)rblk), dim3(kThreads), 0, s>>>(part4, p.splits, n4, (float4*)dw, accumulate);
+    else if (G == 4) splitk_reduce_kernel<4><<<dim3((unsigned)rblk), dim3(kThreads), 0, s>>>(part4, p.splits, n4, (float4*)dw, accumulate);
+    else splitk_reduce_kernel<1><<<dim3((unsigned)rblk), dim3(kThreads), 0, s>>>(part4, p.splits, n4, (float4*)dw, accumulate);
     YFS_CHECK_LAUNCH("splitk_reduce_kernel");
     if (db) {
         float* dbp = (float*)((unsigned char*)workspace + p.partial_bytes);
