@@ -15,6 +15,7 @@ region.  `value` = global images/s.  The JSON line also carries:
   nms           BASELINE config 4 (decode + IoU + class-wise NMS, 1024 images x 845 boxes): images/s and HBM roofline
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -210,6 +211,11 @@ def main():
         opt.step()
         return loss
 
+    # A full (generation-2) Python garbage collection walks every object torch created at import: ~75 ms, which
+    # the GPU spends idle.  It fired once every ~30 steps and cost 2-4 ms/step in short runs; the timed loop
+    # allocates no reference cycles, so collect once and keep the collector off while timing.
+    gc.collect()
+    gc.disable()
     for _ in range(args.warmup):
         step()
     timers = ConvTimers()
@@ -226,6 +232,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gc.enable()
     timers.remove()
     final_loss = float(loss)
     if world > 1:
