@@ -129,6 +129,14 @@ int yfs_leaky_bwd_bf16(const void *dy, const void *y, void *dz, int64_t n, float
 /* fp32 master weight [Cout,K,K,Cin] -> bf16 copy w_bf16 (same layout) and wt_bf16 [Cin,K,K,Cout]
  * flipped (for dgrad); either output may be NULL. */
 int yfs_weight_prep_bf16(const float *w, void *w_bf16, void *wt_bf16, int Cout, int K, int Cin, void *stream);
+/* The same for up to 32 layers in one launch (all Conv2D blocks of feat, :218-254, once per step).  w is the
+ * fp32 master weight, or its bf16 copy when w_is_bf16 != 0.  descs is a host array. */
+typedef struct yfs_weight_desc {
+    const void *w;
+    void *w_bf16, *wt_bf16; /* either may be NULL */
+    int Cout, K, Cin, w_is_bf16;
+} yfs_weight_desc;
+int yfs_weight_prep_batch_bf16(const yfs_weight_desc *descs, int count, void *stream);
 /* im2col for the Cin=3 stem (feat.0, :220): x [N,H,W,Cin] (fp32 if x_is_f32 else bf16) ->
  * cols [N*Ho*Wo, Kpad] bf16 with (kh,kw,ci) order, zero padded to Kpad. */
 int yfs_im2col_bf16(const void *x, int x_is_f32, void *cols, int64_t N, int H, int W, int Cin, int K, int stride,

@@ -4,6 +4,8 @@ Tensor convention: activations are torch tensors of logical shape [N,C,H,W] in `
 format (physically NHWC), dtype bf16; weights are logical [Cout,Cin,K,K] channels_last (physically
 [Cout][K][K][Cin]).  The kernels only ever see the physical layout.
 """
+import ctypes
+
 import torch
 
 from . import _lib as L
@@ -52,6 +54,37 @@ def weight_prep(w, want_w16=True, want_wt16=True):
     L.check(L.lib().yfs_weight_prep_bf16(L.ptr(w), L.ptr(w16), L.ptr(wt16), L.c_int(cout), L.c_int(k), L.c_int(cin),
                                          L.stream()), "yfs_weight_prep_bf16")
     return w16, wt16
+
+
+class _WeightDesc(ctypes.Structure):       # include/yfs.h: yfs_weight_desc
+    _fields_ = [("w", ctypes.c_void_p), ("w_bf16", ctypes.c_void_p), ("wt_bf16", ctypes.c_void_p),
+                ("Cout", ctypes.c_int), ("K", ctypes.c_int), ("Cin", ctypes.c_int), ("w_is_bf16", ctypes.c_int)]
+
+
+def weight_prep_batch(items):
+    """items: list of (w, want_w16, want_wt16) with w the fp32 master weight or its bf16 shadow (logical
+    [Cout,Cin,K,K], channels_last).  One launch for all of them; returns a list of (w16, wt16) — w16 is the shadow
+    itself when the source already is bf16."""
+    out, descs = [], []
+    for w, want_w16, want_wt16 in items:
+        L.require_cuda(w)
+        src16 = w.dtype == torch.bfloat16
+        w = nhwc(w, w.dtype if src16 else torch.float32)
+        cout, cin, k, _ = w.shape
+        w16 = w if src16 else (torch.empty_like(w, dtype=torch.bfloat16) if want_w16 else None)
+        wt16 = _empty_nhwc(cin, cout, k, k, w.device) if want_wt16 else None
+        out.append((w16, wt16))
+        if wt16 is not None or (w16 is not None and not src16):
+            descs.append((w, None if src16 else w16, wt16, cout, k, cin, int(src16)))
+    for i in range(0, len(descs), 32):
+        chunk = descs[i:i + 32]
+        arr = (_WeightDesc * len(chunk))()
+        for a, (w, w16, wt16, cout, k, cin, s16) in zip(arr, chunk):
+            a.w, a.w_bf16, a.wt_bf16 = w.data_ptr(), (w16.data_ptr() if w16 is not None else None), \
+                (wt16.data_ptr() if wt16 is not None else None)
+            a.Cout, a.K, a.Cin, a.w_is_bf16 = cout, k, cin, s16
+        L.check(L.lib().yfs_weight_prep_batch_bf16(arr, L.c_int(len(chunk)), L.stream()), "yfs_weight_prep_batch_bf16")
+    return out
 
 
 def conv_fwd(x, w16, bias, stride=1, slope=0.1):

@@ -43,7 +43,7 @@ def _pool_bwd(x, dy, fuse_leaky, slope=SLOPE):
 class _ConvPlan:
     """What one Conv2D block needs in forward and backward; shared by the per-layer and the chained path."""
 
-    def __init__(self, weight, bias, stride, need_wt):
+    def __init__(self, weight, bias, stride, need_wt, prepared=None):
         cout, cin, k, _ = weight.shape
         self.k, self.stride, self.cin, self.cout = k, stride, cin, cout
         self.stem = cin % 64 != 0
@@ -54,13 +54,19 @@ class _ConvPlan:
             self.w16 = co.stem_weight(weight)
             self.wt16 = None
         else:
-            from .train import bf16_shadow
-            self.w16 = bf16_shadow(weight)      # written by the optimiser step; None without FlatSGD
-            if self.w16 is None:
-                self.w16, self.wt16 = co.weight_prep(weight, want_wt16=need_wt)
-            else:
-                self.wt16 = co.weight_prep(weight, want_w16=False)[1] if need_wt else None
+            self.w16, self.wt16 = prepared if prepared is not None else self.prepare([(weight, need_wt)])[0]
         self.bias = bias.detach().float().contiguous()
+
+    @staticmethod
+    def prepare(weights):
+        """bf16 operand copies for a list of (weight, need_wt) in one launch: [Cout][K][K][Cin] (the optimiser's
+        bf16 shadow when there is one) and, if asked, the transposed tap-reversed copy dgrad reads."""
+        from .train import bf16_shadow
+        items = []
+        for w, need_wt in weights:
+            sh = bf16_shadow(w)                 # written by the optimiser step; None without FlatSGD
+            items.append((sh if sh is not None else w.detach(), True, need_wt))
+        return co.weight_prep_batch(items)
 
     def forward(self, x):
         """x: NHWC bf16 (or fp32/bf16 image for the stem). Returns (gemm_input, y)."""
@@ -196,6 +202,10 @@ class _BackboneFn(torch.autograd.Function):
         L.require_cuda(x)
         plans, acts, gins = [], [], []
         h = x
+        # operand copies of every non-stem layer in one launch
+        convs = [i for i, st in enumerate(stages) if st != "P"]
+        todo = [(params[2 * j], convs[j] > 0) for j in range(len(convs)) if params[2 * j].shape[1] % 64 == 0]
+        prepared = iter(_ConvPlan.prepare(todo))
         pi = 0
         for st in stages:
             if st == "P":
@@ -205,7 +215,8 @@ class _BackboneFn(torch.autograd.Function):
             else:
                 w, b = params[pi], params[pi + 1]
                 pi += 2
-                plan = _ConvPlan(w, b, st, need_wt=len(plans) > 0)
+                plan = _ConvPlan(w, b, st, need_wt=len(plans) > 0,
+                                 prepared=next(prepared) if w.shape[1] % 64 == 0 else None)
                 gin, h = plan.forward(h)
                 plans.append(plan)
                 gins.append(gin)
