@@ -162,6 +162,13 @@ int yfs_maxpool2_fwd_bf16(const void *x, void *y, int64_t N, int H, int W, int C
 /* dx = route(dy) to the first max of each window [* leaky'(x) when fuse_leaky: x is a LeakyReLU output]. */
 int yfs_maxpool2_bwd_bf16(const void *x, const void *dy, void *dx, int64_t N, int H, int W, int C,
                           int fuse_leaky, float slope, void *stream);
+/* The same pool (:216) for a training chain: the forward also saves the window position of every maximum
+ * (idx: uint16 [N*H/2*W/2*C/8], eight 2-bit positions each, first maximum wins as in torch); the backward
+ * then reads y (pooled output, the LeakyReLU mask of the routed element), idx and dy instead of x (H, W are
+ * the INPUT height and width in both). */
+int yfs_maxpool2_fwd_idx_bf16(const void *x, void *y, void *idx, int64_t N, int H, int W, int C, void *stream);
+int yfs_maxpool2_bwd_idx_bf16(const void *y, const void *idx, const void *dy, void *dx, int64_t N, int H, int W,
+                              int C, int fuse_leaky, float slope, void *stream);
 
 /* clip_grad_norm_ + SGD(momentum, weight_decay)  yolo_toy_regressor_torch.py:331-335, :378-381 on flat
  * fp32 arenas (all parameters / gradients / momentum buffers live in one allocation each).

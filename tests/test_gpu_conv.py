@@ -147,3 +147,31 @@ def test_stem_space_to_depth_path(hw, layout, golden_dir):
     dw, db = co.stem_wgrad(xs, co.nhwc(dz.to(DEV), torch.bfloat16))
     _close(dw.view(192, 7, 7, 3).permute(0, 3, 1, 2), wg, "stem wgrad")
     _close(db, bg, "stem bias grad")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,c,hw,fuse", [(2, 64, 8, False), (3, 192, 14, True), (1, 128, 6, True)])
+def test_maxpool_both_paths_vs_oracle(n, c, hw, fuse):
+    """2x2 max pool (reference pool(), yolo_toy_regressor_torch.py:216): the x-based backward and the saved-index
+    backward must agree bit for bit with each other and with the C oracle, ties included (first maximum wins)."""
+    from yolo_from_scratch_amd import model as ym
+    rng = np.random.default_rng(n * 100 + c + hw)
+    x = rng.integers(-3, 4, (n, hw, hw, c)).astype(np.float32) * 0.5          # few distinct values: many ties, zeros
+    dy = rng.standard_normal((n, hw // 2, hw // 2, c)).astype(np.float32)
+    xb = torch.from_numpy(x).to(torch.bfloat16)
+    dyb = torch.from_numpy(dy).to(torch.bfloat16)
+    xd = xb.permute(0, 3, 1, 2).to(DEV)            # logical NCHW, physically NHWC (channels_last)
+    dyd = dyb.permute(0, 3, 1, 2).to(DEV)
+    y1 = ym._pool_fwd(xd)
+    y2, idx = ym._pool_fwd_idx(xd)
+    y_ref = oracle.maxpool2_fwd_nhwc(xb.float().numpy())
+    assert torch.equal(y1, y2)
+    np.testing.assert_array_equal(y1.permute(0, 2, 3, 1).float().cpu().numpy(), y_ref)
+    dx1 = ym._pool_bwd(xd, dyd, fuse_leaky=fuse)
+    dx2 = ym._pool_bwd_idx(y2, idx, dyd, fuse_leaky=fuse)
+    assert torch.equal(dx1, dx2)
+    dx_ref = oracle.maxpool2_bwd_nhwc(xb.float().numpy(), dyb.float().numpy())
+    if fuse:                                       # LeakyReLU'(x) of the routed element, rounded once to bf16
+        scale = np.where(xb.float().numpy() > 0, 1.0, 0.1).astype(np.float32)
+        dx_ref = (torch.from_numpy(dx_ref) * torch.from_numpy(scale)).to(torch.bfloat16).float().numpy()
+    np.testing.assert_array_equal(dx1.permute(0, 2, 3, 1).float().cpu().numpy(), dx_ref)

@@ -29,6 +29,27 @@ def _pool_fwd(x):
     return y
 
 
+def _pool_fwd_idx(x):
+    """Pool forward that also saves the argmax positions (2 bits per element) for _pool_bwd_idx."""
+    x = co.nhwc(x, torch.bfloat16)
+    n, c, h, w = x.shape
+    y = torch.empty((n, c, h // 2, w // 2), device=x.device, dtype=torch.bfloat16, memory_format=co.CL)
+    idx = torch.empty(n * (h // 2) * (w // 2) * (c // 8), device=x.device, dtype=torch.int16)
+    L.check(L.lib().yfs_maxpool2_fwd_idx_bf16(L.ptr(x), L.ptr(y), L.ptr(idx), L.i64(n), L.c_int(h), L.c_int(w), L.c_int(c),
+                                              L.stream()), "yfs_maxpool2_fwd_idx_bf16")
+    return y, idx
+
+
+def _pool_bwd_idx(y, idx, dy, fuse_leaky, slope=SLOPE):
+    dy = co.nhwc(dy, torch.bfloat16)
+    n, c, ho, wo = y.shape
+    dx = torch.empty((n, c, 2 * ho, 2 * wo), device=y.device, dtype=torch.bfloat16, memory_format=co.CL)
+    L.check(L.lib().yfs_maxpool2_bwd_idx_bf16(L.ptr(y), L.ptr(idx), L.ptr(dy), L.ptr(dx), L.i64(n), L.c_int(2 * ho),
+                                              L.c_int(2 * wo), L.c_int(c), L.c_int(1 if fuse_leaky else 0),
+                                              L.c_float(slope), L.stream()), "yfs_maxpool2_bwd_idx_bf16")
+    return dx
+
+
 def _pool_bwd(x, dy, fuse_leaky, slope=SLOPE):
     x = co.nhwc(x, torch.bfloat16)
     dy = co.nhwc(dy, torch.bfloat16)
@@ -209,9 +230,11 @@ class _BackboneFn(torch.autograd.Function):
         pi = 0
         for st in stages:
             if st == "P":
-                h = _pool_fwd(h)
+                h, idx = _pool_fwd_idx(h)
                 plans.append(None)
-                gins.append(None)
+                gins.append(idx)          # a pool's backward needs its output and these 2-bit positions only
+                if acts:
+                    acts[-1] = None       # ... so the full-resolution block output before it can be freed now
             else:
                 w, b = params[pi], params[pi + 1]
                 pi += 2
@@ -238,7 +261,7 @@ class _BackboneFn(torch.autograd.Function):
             g = co.leaky_bwd(g, acts[last], SLOPE)
         for i in range(last, -1, -1):
             if stages[i] == "P":
-                g = _pool_bwd(acts[i - 1], g, fuse_leaky=(i > 0 and stages[i - 1] != "P"))
+                g = _pool_bwd_idx(acts[i], gins[i], g, fuse_leaky=(i > 0 and stages[i - 1] != "P"))
                 continue
             plan = plans[i]
             pi -= 2
