@@ -246,11 +246,14 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) igemm_kernel(IgemmArgs g) {
     constexpr int EPASS = igemm_epi_passes<BM, BN, STAGES>();
     constexpr int PR = BM / EPASS;
     constexpr int TPR = BN / 8;            // threads per output row (8 channels each)
-    constexpr int RPP = NT / TPR;          // rows per sweep of the whole workgroup
-    static_assert(PR % 16 == 0 && PR % RPP == 0, "epilogue slab must hold whole fragments and whole sweeps");
-    const int ec = (tid % TPR) * 8, er = tid / TPR;
+    constexpr bool EVEN = NT % TPR == 0;   // false for the 192-wide tile (24 threads per row): generic item loop
+    constexpr int RPP = EVEN ? NT / TPR : 1;          // rows per sweep of the whole workgroup
+    constexpr int SWEEPS = EVEN ? PR / RPP : (PR * TPR + NT - 1) / NT;
+    static_assert(PR % 16 == 0 && (!EVEN || PR % RPP == 0), "epilogue slab must hold whole fragments and whole sweeps");
+    int ec = (tid % TPR) * 8;
+    const int er = tid / TPR;
     float bv[8];
-    if (EPI == EPI_BIAS_LEAKY) {
+    if (EPI == EPI_BIAS_LEAKY && EVEN) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) bv[j] = g.bias[n0 + ec + j];
     }
@@ -267,8 +270,18 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) igemm_kernel(IgemmArgs g) {
             }
         __syncthreads();
 #pragma unroll
-        for (int p = 0; p < PR / RPP; ++p) {
-            const int row = er + p * RPP;
+        for (int p = 0; p < SWEEPS; ++p) {
+            int row = er + p * RPP;
+            if (!EVEN) {
+                const int item = tid + p * NT;
+                if (item >= PR * TPR) continue;
+                row = item / TPR;
+                ec = (item - row * TPR) * 8;
+                if (EPI == EPI_BIAS_LEAKY) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bv[j] = g.bias[n0 + ec + j];
+                }
+            }
             int m = m0 + pass * PR + row;
             if (m >= Mc) continue;
             if (SUB) {   // class-grid pixel -> pixel of the full output
@@ -346,11 +359,12 @@ int launch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
 // (four-pass epilogue); it is chosen by the round-count model below.  Tried and rejected: 256x128 / 8 waves /
 // 3 stages (875-990), 32-deep rings at four workgroups per CU (790-880), 32-deep 4/5-stage rings (780-870),
 // 256x128 / 4 waves / 32-deep (810-980), issuing the loads between the MFMAs instead of in a burst (-6 %).
-// 128x64 serves the 192-channel outputs.  YFS_IGEMM_TILE=128|256|2562 forces a variant for benchmarking.
+// 128x192 serves the 192-channel outputs (pixel tile read once instead of three times with 128x64).  YFS_IGEMM_TILE=128|256|2562 forces a variant for benchmarking.
 template <int EPI, bool SUB>
 int dispatch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
-    if (g.NOUT % 128 != 0) return launch_igemm<128, 64, 2, 2, 2, EPI, SUB>(g, s, name);
     static const int force = [] { const char* e = getenv("YFS_IGEMM_TILE"); return e ? atoi(e) : 0; }();
+    if (g.NOUT % 192 == 0 && g.NOUT % 128 != 0 && force != 64) return launch_igemm<128, 192, 2, 2, 2, EPI, SUB>(g, s, name);
+    if (g.NOUT % 128 != 0) return launch_igemm<128, 64, 2, 2, 2, EPI, SUB>(g, s, name);
     if (force == 256) return launch_igemm<256, 128, 4, 2, 3, EPI, SUB>(g, s, name);
     bool big = force == 2562;
     if (force == 0 && !SUB) {
