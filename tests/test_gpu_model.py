@@ -169,3 +169,45 @@ def test_train_one_epoch_and_evaluate_surface():
         l1 = yt.train_one_epoch(net, loader, DEV, opt, None, loss_fn, 1.0)
     vl, viou = yt.evaluate(net, loader, DEV, loss_fn)
     assert l1 < l0 and vl < l0 and 0.0 <= viou <= 1.0
+
+
+def test_config1_forward_loss_decode_nms_vs_cpu_oracle():
+    """BASELINE configs[0]: synthetic 224x224, batch 8, S=7 B=2 C=20 — backbone +
+    build-defined head -> composite loss -> decode -> class-wise NMS, every stage against the CPU oracle.
+    The model output is compared at the bf16 tolerance; the fp32 stages are then checked on the GPU's own
+    output (identical inputs on both sides): loss/grad/boxes 1e-5, kept indices bit for bit."""
+    import oracle
+    from yolo_from_scratch_amd import synth
+    import yolo_from_scratch_amd as y
+    N = 8
+    x = torch.rand(N, 3, 224, 224, generator=torch.Generator().manual_seed(0))
+    params = model_ref.init_params(seed=0, head_out=1470, in_hw=224)
+    torch.manual_seed(0)
+    net = ym.YoloRegressorModel(head_out=1470, image_size=224).to(DEV).eval()
+    for k, v in net.state_dict().items():                       # same construction order => same weights
+        assert torch.equal(v.cpu().contiguous(), params[k]), k
+    with torch.no_grad():
+        ref = model_ref.head_forward(model_ref.feat_forward(x, params), params)
+        out = net(x.to(DEV)).float()
+    assert out.shape == ref.shape == (N, 1470)
+    assert _rel(out, ref) < 4e-2                                  # 24 bf16 layers + 2 bf16 linears
+    pred = out.view(N, 7, 7, 30)
+    target = synth.v1_targets(N, seed=1)
+    # fused loss + gradient
+    lo, go = oracle.yolov1_loss(pred.cpu().numpy(), target)
+    crit = y.YoloV1Loss(7, 2, 20)
+    p = pred.clone().requires_grad_(True)
+    loss = crit(p, torch.from_numpy(target).to(DEV))
+    loss.backward()
+    assert abs(float(loss) - lo[0]) <= 1e-5 * abs(lo[0])
+    np.testing.assert_allclose(p.grad.cpu().numpy(), go, rtol=1e-5, atol=1e-6)
+    # decode -> score -> NMS
+    b, s, c = y.decode_v1(pred, B=2, C=20)
+    bo, so, co_ = oracle.decode_v1(pred.cpu().numpy(), 2, 20)
+    np.testing.assert_allclose(b.cpu().numpy(), bo, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(s.cpu().numpy(), so, rtol=1e-5, atol=1e-7)
+    np.testing.assert_array_equal(c.cpu().numpy(), co_)
+    keep, cnt = y.nms(b, s, c, 0.05, 0.5)
+    keep_o, cnt_o = oracle.nms(b.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy(), 0.05, 0.5)
+    np.testing.assert_array_equal(cnt.cpu().numpy(), cnt_o)
+    np.testing.assert_array_equal(keep.cpu().numpy(), keep_o)
