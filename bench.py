@@ -31,6 +31,8 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0         # HBM3E spec, same table
 BATCH = 64
+LOSS_BYTES_PER_IMG = 17640    # read pred + read target + write grad, 3 x 1470 x 4
+ASSIGN_BYTES_PER_IMG = 32750  # gts 640 + decoded preds 13,520 + masks 1,690 + targets 16,900
 NMS_BYTES_PER_IMG = 108160    # raw head 84,500 + boxes/score/class 20,280 + kept indices 3,380
 
 
@@ -120,7 +122,7 @@ def cpu_baseline_train(sample_batch=4, steps=2):
     dt = time.perf_counter() - t0
     return {"value": round(sample_batch * steps / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"{steps} train steps at batch {sample_batch}, 448x448, fp32 torch-CPU restatement "
-                      f"(oracle/model_ref.py + oracle yolov1_loss), 1 warm-up step untimed"}
+                      f"(oracle/model_ref.py + oracle yolov1_loss), 1 warm-up step untimed, on {_cpu_model()}"}
 
 
 def nms_bench(device, iters=20):
@@ -148,6 +150,93 @@ def nms_bench(device, iters=20):
     return out
 
 
+def _time_ms(fn, iters, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def _hbm_record(nbytes, ms):
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(gbs, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(gbs / PEAK_HBM_GBS, 5), "traffic": None}
+
+
+def loss_bench(device, N=65536):
+    """Kernel set 2 at the batch where its HBM fraction means something (N=64 moves 1.1 MB and is
+    latency-bound; N=65,536 moves 1.16 GB).  Calls the C ABI directly: forward + gradient in one launch."""
+    from yolo_from_scratch_amd import _lib as L
+    g = torch.Generator(device="cpu").manual_seed(3)
+    pred = torch.rand(4096, 7, 7, 30, generator=g).repeat(N // 4096, 1, 1, 1).to(device)
+    tgt = torch.from_numpy(np.tile(__import__("yolo_from_scratch_amd.synth", fromlist=["x"]).v1_targets(4096, seed=1),
+                                   (N // 4096, 1, 1, 1))).to(device)
+    ws_bytes = L.lib().yfs_yolov1_loss_workspace_bytes(L.i64(N), L.c_int(7))
+    ws = torch.empty(ws_bytes // 4 + 1, device=device, dtype=torch.float32)
+    out = torch.empty(5, device=device, dtype=torch.float32)
+    grad = torch.empty_like(pred)
+
+    def run():
+        L.check(L.lib().yfs_yolov1_loss_fwd_bwd_f32(L.ptr(pred), L.ptr(tgt), L.i64(N), L.c_int(7), L.c_int(2), L.c_int(20),
+                                                    L.c_float(5.0), L.c_float(0.5), L.ptr(out), L.ptr(grad), L.ptr(ws),
+                                                    L.c_size(ws_bytes), L.stream()), "yfs_yolov1_loss_fwd_bwd_f32")
+    ms = _time_ms(run, 20)
+    return {"metric": "fused YOLOv1 loss + gradient images/sec (S=7 B=2 C=20, batch %d)" % N,
+            "value": round(N / (ms * 1e-3), 1), "unit": "images/s", "ms_per_batch": round(ms, 4), "dtype": "f32",
+            "roofline": _hbm_record(N * LOSS_BYTES_PER_IMG, ms)}
+
+
+def assign_bench(device, N=8192, S=13, G=32):
+    """Kernel set 4: YOLOv2 target assignment + ignore mask, S=13, A=5, G=32 padded gts per image."""
+    import yolo_from_scratch_amd as y
+    from yolo_from_scratch_amd import synth
+    gt = torch.from_numpy(synth.gt_boxes(N, G=G, seed=5)).to(device)
+    anchors = torch.from_numpy(synth.VOC_ANCHORS).to(device)
+    pred = torch.rand(N, S * S * 5, 4, generator=torch.Generator().manual_seed(6)).to(device)
+    ms = _time_ms(lambda: y.assign_targets_v2(gt, anchors, S, pred, 0.6), 20)
+    return {"metric": "YOLOv2 target assignment images/sec (S=13, A=5, G=32, batch %d)" % N,
+            "value": round(N / (ms * 1e-3), 1), "unit": "images/s", "ms_per_batch": round(ms, 4), "dtype": "f32",
+            "roofline": _hbm_record(N * ASSIGN_BYTES_PER_IMG, ms)}
+
+
+def measured_ceilings(device):
+    """What this box sustains, next to the vendor peaks the roofline fractions are priced against."""
+    import ctypes
+    from yolo_from_scratch_amd import _lib as L
+    a = torch.empty(1 << 30, device=device, dtype=torch.uint8)
+    b = torch.empty_like(a)
+    ms = _time_ms(lambda: b.copy_(a), 10)
+    hbm = 2 * a.numel() / (ms * 1e-3) / 1e9
+    del a, b
+    flop = ctypes.c_double(0.0)
+    scratch = torch.zeros(4, device=device)
+    blocks, iters = 256 * 8, 4096
+
+    def run():
+        L.check(L.lib().yfs_probe_mfma_bf16(L.c_int(iters), L.c_int(blocks), ctypes.byref(flop), L.ptr(scratch), L.stream()),
+                "yfs_probe_mfma_bf16")
+    ms = _time_ms(run, 5, warm=2)
+    return {"hbm_copy_GBps": round(hbm, 1), "mfma_bf16_TFLOPs": round(flop.value / (ms * 1e-3) / 1e12, 1),
+            "note": "device-to-device copy of 1 GiB (read + write bytes); register-only v_mfma_f32_16x16x32_bf16 loop, "
+                    "8 workgroups x 4 waves per CU, at the clock the chip holds under that load"}
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
 def cpu_baseline_nms(sample=64):
     import oracle
     from yolo_from_scratch_amd import synth
@@ -160,7 +249,7 @@ def cpu_baseline_nms(sample=64):
         reps += 1
     dt = time.perf_counter() - t0
     return {"value": round(sample * reps / dt, 1), "unit": "images/s", "cores": 1, "kind": "port",
-            "sample": f"{reps} passes over {sample} images of config 4 (C oracle, scalar)"}
+            "sample": f"{reps} passes over {sample} images of config 4 (C oracle, scalar) on {_cpu_model()}"}
 
 
 def main():
@@ -268,6 +357,9 @@ def main():
             rec["nms"] = nms_bench(device)
             if not args.no_cpu_baseline:
                 rec["nms"]["cpu_baseline"] = cpu_baseline_nms()
+            rec["loss"] = loss_bench(device)
+            rec["assign"] = assign_bench(device)
+            rec["roofline"]["measured_ceilings"] = measured_ceilings(device)
         if world == 1 and not args.no_cpu_baseline:
             del model, opt
             torch.cuda.empty_cache()

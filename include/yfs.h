@@ -183,6 +183,11 @@ int yfs_sumsq_f32(const float *g, int64_t n, float *sumsq_out, void *workspace, 
 int yfs_sgd_step_f32(float *p, const float *g, float *buf, int64_t n, const float *sumsq, float max_norm,
                      float lr, float momentum, float weight_decay, int first_step, void *p_bf16, void *stream);
 
+/* Measurement aid, no reference counterpart: enqueue a register-only bf16 MFMA loop (blocks x 4 waves x iters x
+ * 16 MFMAs of 16x16x32) and return the FLOPs it performs in *flop_out; the caller times it.  scratch: >= 4 bytes of
+ * device memory (never written in practice).  bench.py prints the resulting rate next to the vendor peak. */
+int yfs_probe_mfma_bf16(int iters, int blocks, double *flop_out, void *scratch, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
