@@ -9,16 +9,6 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kMaxD = 40;   // 5B + C supported by the LDS carve
 
-__device__ __forceinline__ int stage_floats(const float* __restrict__ src, int len, float* lds, int tid) {
-    const uintptr_t addr = reinterpret_cast<uintptr_t>(src);
-    const int skew = (int)((addr >> 2) & 3);
-    const float4* base = reinterpret_cast<const float4*>(addr - (uintptr_t)skew * 4);
-    const int nq = (skew + len + 3) >> 2;
-    float4* l4 = reinterpret_cast<float4*>(lds);
-    for (int q = tid; q < nq; q += kThreads) l4[q] = base[q];
-    return skew;
-}
-
 // lds[skew + i] -> dst[i], i in [0,len): 16-byte stores where source and destination phases agree.
 __device__ __forceinline__ void unstage_floats(float* __restrict__ dst, int len, const float* lds, int skew, int tid) {
     const int dskew = (int)((reinterpret_cast<uintptr_t>(dst) >> 2) & 3);
@@ -58,9 +48,10 @@ __global__ void __launch_bounds__(kThreads) yolov1_loss_kernel(const float* __re
     const int64_t c0 = (int64_t)blockIdx.x * kThreads;
     const int nc = (int)((ncells - c0) < kThreads ? (ncells - c0) : kThreads);
     float* lp = lds;
-    float* lt = lds + (kThreads * D + 8);
-    const int sp = stage_floats(pred + c0 * D, nc * D, lp, tid);
-    const int st = stage_floats(target + c0 * D, nc * D, lt, tid);
+    float* lt = lds + YFS_STAGE_FLOATS(kThreads * D);
+    const int sp = yfs_stage_floats_dma(pred + c0 * D, nc * D, lp, kThreads / 64);
+    const int st = yfs_stage_floats_dma(target + c0 * D, nc * D, lt, kThreads / 64);
+    yfs_stage_wait();
     __syncthreads();
 
     float coord = 0.0f, objl = 0.0f, noobj = 0.0f, clsl = 0.0f;
@@ -197,7 +188,7 @@ YFS_API int yfs_yolov1_loss_fwd_bwd_f32(const float* pred, const float* target, 
     hipStream_t s = (hipStream_t)stream;
     const int64_t ncells = N * S * S;
     const int64_t nblk = yfs_cdiv(ncells, kThreads);
-    const size_t lds = 2 * ((size_t)kThreads * D + 8) * sizeof(float);
+    const size_t lds = 2 * (size_t)YFS_STAGE_FLOATS(kThreads * D) * sizeof(float);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)yolov1_loss_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         YFS_REQUIRE(e == hipSuccess, YFS_ERR_LAUNCH, "yfs_yolov1_loss_fwd_bwd_f32: cannot reserve %zu bytes of LDS", lds);

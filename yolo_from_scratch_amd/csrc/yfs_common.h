@@ -38,6 +38,35 @@ __device__ __forceinline__ float yfs_wave_sum(float v) {
     return v;   // lane 0 holds the sum, fixed reduction tree => deterministic
 }
 
+// Stage the global floats [src, src+len) into LDS asynchronously (global -> LDS DMA, `buffer_load ... lds`):
+// one wave-instruction moves 1 KiB (lane i lands at chunk base + 16 i), no staging registers, and every
+// instruction of the copy is issued before anything is waited for.  A per-thread `load; wait; ds_write` loop
+// (what the compiler makes of the obvious copy loop: flat loads with vmcnt(0) after each) pays one HBM round
+// trip per 16 bytes and left these HBM-bound kernels 80 % idle (SQ_WAIT_ANY / SQ_WAVE_CYCLES).
+// `src` is only 4-byte aligned in general (per-image offsets such as n*21125 floats): the copy starts at the
+// enclosing 16-byte boundary and src[i] lands at lds[skew + i] (skew returned).  Bytes past the end are
+// written as zeros up to the next 1 KiB boundary, so `lds` must have room for YFS_STAGE_FLOATS(len) floats.
+// The caller must execute `yfs_stage_wait()` and a barrier before reading the LDS image.
+#define YFS_STAGE_FLOATS(len) ((((len) + 3 + 4) * 4 + 1023) / 1024 * 256)
+__device__ __forceinline__ int yfs_stage_floats_dma(const float* __restrict__ src, int len, float* lds, int nwaves) {
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(src);
+    const int skew = (int)((addr >> 2) & 3);
+    const unsigned nbytes = (unsigned)(((skew + len + 3) >> 2) << 4);
+    const __amdgpu_buffer_rsrc_t r =
+        __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(addr - (uintptr_t)skew * 4), 0, (int)nbytes, 0x00020000);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nchunks = (int)((nbytes + 1023u) >> 10);
+    unsigned char* lb = reinterpret_cast<unsigned char*>(lds);
+    for (int c = wave; c < nchunks; c += nwaves) {
+        const unsigned off = (unsigned)c * 1024u + (unsigned)lane * 16u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr)(lb + c * 1024), 16, off, 0, 0, 0);
+    }
+    return skew;
+}
+__device__ __forceinline__ void yfs_stage_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // IoU in the op order of iou_xywh_torch (reference yolo_toy_regressor_torch.py:159-182).
 // Must stay free of FMA contraction: files that include this for mask decisions are built
 // with -ffp-contract=off.
