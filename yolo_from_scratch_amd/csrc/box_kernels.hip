@@ -8,22 +8,6 @@ namespace {
 
 constexpr int kThreads = 256;
 
-// ------------------------------------------------------------------------------------------
-// Stage the global floats [src, src+len) into LDS with 16-byte loads.  `src` is only 4-byte
-// aligned in general (per-image offsets such as n*21125 floats), so the copy starts at the
-// enclosing 16-byte boundary; the element src[i] lands at lds[skew + i].  The extra <=12 bytes
-// on either side lie in the same 16-byte granule as a valid element, hence inside the allocation.
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int stage_floats(const float* __restrict__ src, int len, float* lds, int tid) {
-    const uintptr_t addr = reinterpret_cast<uintptr_t>(src);
-    const int skew = (int)((addr >> 2) & 3);
-    const float4* base = reinterpret_cast<const float4*>(addr - (uintptr_t)skew * 4);
-    const int nq = (skew + len + 3) >> 2;
-    float4* l4 = reinterpret_cast<float4*>(lds);
-    for (int q = tid; q < nq; q += kThreads) l4[q] = base[q];
-    return skew;
-}
-
 struct Decoded {
     float x, y, w, h, score;
     int cls;
@@ -203,7 +187,8 @@ __global__ void __launch_bounds__(kThreads) decode_grid_kernel(const float* __re
     const int D = 5 + C;
     const int64_t b0 = (int64_t)blockIdx.x * bpb;
     const int nb = (int)((nboxes - b0) < bpb ? (nboxes - b0) : bpb);
-    const int skew = stage_floats(raw + b0 * D, nb * D, lds, threadIdx.x);
+    const int skew = yfs_stage_floats_dma(raw + b0 * D, nb * D, lds, kThreads / 64);
+    yfs_stage_wait();
     __syncthreads();
     const int t = threadIdx.x;
     if (t < nb) {
@@ -234,7 +219,8 @@ __global__ void __launch_bounds__(kThreads) decode_v1_kernel(const float* __rest
     const int D = 5 * B + C;
     const int64_t c0 = (int64_t)blockIdx.x * kThreads;
     const int nc = (int)((ncells - c0) < kThreads ? (ncells - c0) : kThreads);
-    const int skew = stage_floats(pred + c0 * D, nc * D, lds, threadIdx.x);
+    const int skew = yfs_stage_floats_dma(pred + c0 * D, nc * D, lds, kThreads / 64);
+    yfs_stage_wait();
     __syncthreads();
     const int t = threadIdx.x;
     if (t >= nc) return;
@@ -324,7 +310,8 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
         const float* rimg = g.raw + n * (int64_t)A * D;
         for (int b0 = 0; b0 < A; b0 += g.bpc) {
             const int nb = (A - b0) < g.bpc ? (A - b0) : g.bpc;
-            const int skew = stage_floats(rimg + (int64_t)b0 * D, nb * D, rawlds, tid);
+            const int skew = yfs_stage_floats_dma(rimg + (int64_t)b0 * D, nb * D, rawlds, kThreads / 64);
+            yfs_stage_wait();
             __syncthreads();
             for (int t = tid; t < nb; t += kThreads) {
                 const int bi = b0 + t;
@@ -470,7 +457,7 @@ size_t nms_lds_bytes(int cap, bool fused, int bpc, int D) {
     size_t head = 28 * (size_t)cap + 16;
     size_t tail = 28 * (size_t)cap;
     if (fused) {
-        size_t rawb = ((size_t)bpc * D + 8) * 4;
+        size_t rawb = (size_t)YFS_STAGE_FLOATS(bpc * D) * 4;
         if (rawb > tail) tail = rawb;
     }
     return head + tail;
@@ -550,7 +537,7 @@ YFS_API int yfs_decode_grid_f32(const float* raw, int64_t N, int S, int A, int C
     const int D = 5 + C;
     const int bpb = pick_boxes_per_block(D);
     const int64_t nboxes = N * S * S * A;
-    const size_t lds = ((size_t)bpb * D + 8) * 4;
+    const size_t lds = (size_t)YFS_STAGE_FLOATS(bpb * D) * 4;
     decode_grid_kernel<<<dim3((unsigned)yfs_cdiv(nboxes, bpb)), dim3(kThreads), lds, (hipStream_t)stream>>>(
         raw, nboxes, S, A, C, anchors, bpb, (float4*)boxes, score, cls, all_scores);
     YFS_CHECK_LAUNCH("decode_grid_kernel");
@@ -564,7 +551,7 @@ YFS_API int yfs_decode_v1_f32(const float* pred, int64_t N, int S, int B, int C,
                 "yfs_decode_v1_f32: bad shape N=%lld S=%d B=%d C=%d (5B+C <= 40)", (long long)N, S, B, C);
     const int D = 5 * B + C;
     const int64_t ncells = N * S * S;
-    const size_t lds = ((size_t)kThreads * D + 8) * 4;
+    const size_t lds = (size_t)YFS_STAGE_FLOATS(kThreads * D) * 4;
     decode_v1_kernel<<<dim3((unsigned)yfs_cdiv(ncells, kThreads)), dim3(kThreads), lds, (hipStream_t)stream>>>(
         pred, ncells, S, B, C, (float4*)boxes, score, cls);
     YFS_CHECK_LAUNCH("decode_v1_kernel");
