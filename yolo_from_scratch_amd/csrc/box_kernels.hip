@@ -269,42 +269,83 @@ struct NmsArgs {
     int32_t* count;
     int A;                   // boxes per image
     int cap;                 // A rounded up to 64
+    int npow;                // power of two >= cap (bitonic sort length bound)
     int bpc;                 // fused: boxes per staged chunk
     float score_thr, iou_thr;
 };
 
-__device__ __forceinline__ unsigned long long make_key(float s, int idx) {
+// 64-bit sort key: [class : 21][~monotone(score) : 32][slot : 11].  Ascending order = class-major, then descending
+// score, then ascending slot; slots are handed out in box-index order, so the last field is the index tie-break.
+constexpr int kSlotBits = 11;                 // YFS_NMS_MAX_BOXES = 2048
+constexpr unsigned long long kSlotMask = (1ull << kSlotBits) - 1ull;
+constexpr int kClsShift = 32 + kSlotBits;
+__device__ __forceinline__ unsigned score_bits(float s) {
     unsigned u = __float_as_uint(s);
     u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // monotone float -> uint
-    return ((unsigned long long)(~u) << 32) | (unsigned)idx;   // ascending key = descending score, ascending idx
+    return ~u;                                         // ascending = descending score
+}
+__device__ __forceinline__ unsigned long long make_key(int cls, float s, int slot) {
+    return ((unsigned long long)((unsigned)cls & 0x1FFFFFu) << kClsShift) | ((unsigned long long)score_bits(s) << kSlotBits) |
+           (unsigned)slot;
+}
+
+// In-place ascending bitonic sort of n = 2^k 64-bit keys in LDS by the whole workgroup (one compare-exchange per
+// thread and step; n log^2 n / 4 exchanges instead of the n^2 compares of a rank sort).
+__device__ __forceinline__ void bitonic_sort(unsigned long long* a, int n, int tid) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (n >> 1); t += kThreads) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int p = i | j;
+                const unsigned long long x = a[i], y = a[p];
+                const bool up = (i & k) == 0;
+                if ((x > y) == up) { a[i] = y; a[p] = x; }
+            }
+            __syncthreads();
+        }
+    }
 }
 
 template <bool FUSED>
 __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int wcnt[2][kThreads / 64];
+    __shared__ int ctl[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t n = blockIdx.x;
-    const int A = g.A, cap = g.cap;
-    // carve (all offsets multiples of 16)
-    unsigned long long* key = reinterpret_cast<unsigned long long*>(smem);          // 8*cap   (kept list aliases)
-    float4* cbox = reinterpret_cast<float4*>(smem + 8 * (size_t)cap);                // 16*cap  (mask aliases)
-    int* ccls = reinterpret_cast<int*>(smem + 24 * (size_t)cap);                     // 4*cap
-    int* ctl = reinterpret_cast<int*>(smem + 28 * (size_t)cap);                      // 16 bytes of counters
-    unsigned char* tail = smem + 28 * (size_t)cap + 16;
-    float4* sbox = reinterpret_cast<float4*>(tail);                                  // 16*cap
-    int* scls = reinterpret_cast<int*>(tail + 16 * (size_t)cap);                     // 4*cap
-    int* sidx = reinterpret_cast<int*>(tail + 20 * (size_t)cap);                     // 4*cap
-    int* ord2 = reinterpret_cast<int*>(tail + 24 * (size_t)cap);                     // 4*cap
-    float* rawlds = reinterpret_cast<float*>(tail);                                  // fused staging aliases sorted arrays
-    // key / cbox / ccls are dead after the sort; their 28*cap bytes are reused:
-    int* kept = reinterpret_cast<int*>(smem);                                        // 4*cap
-    int* kflag = kept + cap;                                                         // 4*cap
-    int* segs = kflag + cap;                                                         // 4*cap
+    const int A = g.A, cap = g.cap, npow = g.npow;
+    // carve (all offsets multiples of 16): candidates live at their slot for the whole kernel
+    float4* cbox = reinterpret_cast<float4*>(smem);                                           // 16*cap  corners
+    int* cidx = reinterpret_cast<int*>(smem + 16 * (size_t)cap);                               // 4*cap   box index
+    unsigned long long* key = reinterpret_cast<unsigned long long*>(smem + 20 * (size_t)cap);  // 8*npow
+    unsigned char* tail = smem + 20 * (size_t)cap + 8 * (size_t)npow;
+    int* kflag = reinterpret_cast<int*>(tail);                                                 // 4*cap
+    int* segs = kflag + cap;                                                                   // 4*cap
+    float* rawlds = reinterpret_cast<float*>(tail);   // fused: raw-head staging, dead before kflag / segs are used
 
-    if (tid == 0) { ctl[0] = 0; }
-    __syncthreads();
-
-    // ---- A: filter / decode ----
+    // ---- A: decode / filter, candidates compacted in box-index order (ballot prefix, no atomics) ----
+    int K = 0;
+    int par = 0;
+    auto compact = [&](bool pass, int bi, float4 corners, float score, int cls) {
+        const unsigned long long bal = __ballot(pass);
+        if (lane == 0) wcnt[par][wave] = __builtin_popcountll(bal);
+        __syncthreads();
+        int off = K, tot = 0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) {
+            const int cw = wcnt[par][w];
+            off += w < wave ? cw : 0;
+            tot += cw;
+        }
+        if (pass) {
+            const int slot = off + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+            cbox[slot] = corners;
+            cidx[slot] = bi;
+            key[slot] = make_key(cls, score, slot);
+        }
+        K += tot;
+        par ^= 1;
+    };
     if (FUSED) {
         const int D = 5 + g.C;
         const float* rimg = g.raw + n * (int64_t)A * D;
@@ -313,111 +354,110 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
             const int skew = yfs_stage_floats_dma(rimg + (int64_t)b0 * D, nb * D, rawlds, kThreads / 64);
             yfs_stage_wait();
             __syncthreads();
-            for (int t = tid; t < nb; t += kThreads) {
+            for (int t0 = 0; t0 < nb; t0 += kThreads) {
+                const int t = t0 + tid;
+                bool pass = false;
+                float4 corners = make_float4(0.f, 0.f, 0.f, 0.f);
+                float sc = 0.f;
+                int cl = 0;
                 const int bi = b0 + t;
-                const int a = bi % g.A_anch, cell = bi / g.A_anch;
-                Decoded d = decode_one(rawlds + skew + t * D, g.C, cell / g.S, cell % g.S, g.S, g.anchors[2 * a],
-                                       g.anchors[2 * a + 1]);
-                const int64_t o = n * A + bi;
-                g.boxes_out[o] = make_float4(d.x, d.y, d.w, d.h);
-                g.score_out[o] = d.score;
-                g.cls_out[o] = d.cls;
-                if (d.score >= g.score_thr) {
-                    int slot = atomicAdd(&ctl[0], 1);
-                    key[slot] = make_key(d.score, bi);
-                    cbox[slot] = make_float4(d.x - 0.5f * d.w, d.y - 0.5f * d.h, d.x + 0.5f * d.w, d.y + 0.5f * d.h);
-                    ccls[slot] = d.cls;
+                if (t < nb) {
+                    const int a = bi % g.A_anch, cell = bi / g.A_anch;
+                    Decoded d = decode_one(rawlds + skew + t * D, g.C, cell / g.S, cell % g.S, g.S, g.anchors[2 * a],
+                                           g.anchors[2 * a + 1]);
+                    const int64_t o = n * A + bi;
+                    g.boxes_out[o] = make_float4(d.x, d.y, d.w, d.h);
+                    g.score_out[o] = d.score;
+                    g.cls_out[o] = d.cls;
+                    pass = d.score >= g.score_thr;
+                    corners = make_float4(d.x - 0.5f * d.w, d.y - 0.5f * d.h, d.x + 0.5f * d.w, d.y + 0.5f * d.h);
+                    sc = d.score;
+                    cl = d.cls;
                 }
+                compact(pass, bi, corners, sc, cl);
             }
-            __syncthreads();
+            __syncthreads();   // everyone is done with rawlds before the next chunk lands in it
         }
     } else {
-        for (int i = tid; i < A; i += kThreads) {
-            const int64_t o = n * A + i;
-            float s = g.score_in[o];
-            if (s >= g.score_thr) {
-                float4 v = g.boxes_in[o];
-                int slot = atomicAdd(&ctl[0], 1);
-                key[slot] = make_key(s, i);
-                cbox[slot] = make_float4(v.x - 0.5f * v.z, v.y - 0.5f * v.w, v.x + 0.5f * v.z, v.y + 0.5f * v.w);
-                ccls[slot] = g.cls_in[o];
+        for (int i0 = 0; i0 < A; i0 += kThreads) {
+            const int i = i0 + tid;
+            bool pass = false;
+            float4 corners = make_float4(0.f, 0.f, 0.f, 0.f);
+            float sc = 0.f;
+            int cl = 0;
+            if (i < A) {
+                const int64_t o = n * A + i;
+                sc = g.score_in[o];
+                pass = sc >= g.score_thr;
+                if (pass) {
+                    const float4 v = g.boxes_in[o];
+                    corners = make_float4(v.x - 0.5f * v.z, v.y - 0.5f * v.w, v.x + 0.5f * v.z, v.y + 0.5f * v.w);
+                    cl = g.cls_in[o];
+                }
             }
+            compact(pass, i, corners, sc, cl);
         }
         __syncthreads();
     }
-    const int K = ctl[0];
 
-    // ---- B: two rank sorts in one sweep ----
-    // r  = rank by (score desc, index asc): the output order;
-    // cm = rank by (class, then the same key): boxes of one class become one contiguous segment, in score order.
+    // ---- B: sort by (class, score desc, index): every class becomes one contiguous, score-ordered segment ----
     // Class-wise NMS never compares boxes of different classes, so suppression runs per segment: with ~450
     // candidates in 20 classes that is ~5 K IoU evaluations per image instead of the ~100 K of an all-pairs mask.
-    for (int c = tid; c < K; c += kThreads) {
-        const unsigned long long k = key[c];
-        const int cc = ccls[c];
-        int r = 0, cm = 0;
-        for (int j = 0; j < K; ++j) {
-            const bool lt = key[j] < k;
-            const int cj = ccls[j];
-            r += lt ? 1 : 0;
-            cm += (cj < cc || (cj == cc && lt)) ? 1 : 0;
-        }
-        sbox[r] = cbox[c];
-        scls[r] = cc;
-        sidx[r] = (int)(unsigned)(k & 0xffffffffull);
-        ord2[cm] = r;
-    }
-    if (tid == 0) ctl[2] = 0;
-    __syncthreads();   // key/cbox/ccls are dead from here
+    int ns = 2;
+    while (ns < K) ns <<= 1;                       // K <= cap <= npow
+    for (int p = K + tid; p < ns; p += kThreads) key[p] = ~0ull;
     for (int p = tid; p < K; p += kThreads) kflag[p] = 0;
+    if (tid == 0) ctl[2] = 0;
+    __syncthreads();
+    bitonic_sort(key, ns, tid);
     for (int p = tid; p < K; p += kThreads)
-        if (p == 0 || scls[ord2[p]] != scls[ord2[p - 1]]) segs[atomicAdd(&ctl[2], 1)] = p;   // order is irrelevant
+        if (p == 0 || (key[p] >> kClsShift) != (key[p - 1] >> kClsShift)) segs[atomicAdd(&ctl[2], 1)] = p;   // any order
     __syncthreads();
     const int nseg = ctl[2];
 
     // ---- C: greedy suppression, one wave per class segment ----
     for (int sg = wave; sg < nseg; sg += kThreads / 64) {
         const int p0 = segs[sg];
-        const int c = scls[ord2[p0]];
-        int n = 0;   // segment length: leading run of class c from p0
+        const unsigned long long c = key[p0] >> kClsShift;
+        int len = 0;   // segment length: leading run of class c from p0
         for (int base = p0; base < K; base += 64) {
             const int p = base + lane;
-            const bool same = p < K && scls[ord2[p]] == c;
+            const bool same = p < K && (key[p] >> kClsShift) == c;
             const unsigned long long bal = __ballot(same);
-            if (bal == ~0ull) { n += 64; continue; }
-            n += __builtin_ctzll(~bal);
+            if (bal == ~0ull) { len += 64; continue; }
+            len += __builtin_ctzll(~bal);
             break;
         }
-        if (n <= 64) {
+        if (len <= 64) {
             // member `lane` lives in this lane's registers; `removed` is wave-uniform
-            const bool mine = lane < n;
-            const int rj = mine ? ord2[p0 + lane] : 0;
-            const float4 q = sbox[rj];
+            const bool mine = lane < len;
+            const int sj = mine ? (int)(key[p0 + lane] & kSlotMask) : 0;
+            const float4 q = cbox[sj];
             unsigned long long removed = 0;
-            for (int i = 0; i < n; ++i) {
+            for (int i = 0; i < len; ++i) {
                 if ((removed >> i) & 1ull) continue;
-                const float4 pb = sbox[__shfl(rj, i, 64)];
+                const float4 pb = cbox[__shfl(sj, i, 64)];
                 const float v = yfs_iou_corners(pb.x, pb.y, pb.z, pb.w, q.x, q.y, q.z, q.w);
                 removed |= __ballot(mine && lane > i && v > g.iou_thr);
             }
-            if (mine && !((removed >> lane) & 1ull)) kflag[rj] = 1;
+            if (mine && !((removed >> lane) & 1ull)) kflag[sj] = 1;
         } else {
             // member lane + 64 t <-> bit t of this lane's `rem`
-            const int T = (n + 63) >> 6;
+            const int T = (len + 63) >> 6;
             unsigned long long rem = 0;
-            for (int i = 0; i < n; ++i) {
+            for (int i = 0; i < len; ++i) {
                 const int ti = i >> 6, own = i & 63;
                 const unsigned lo = (unsigned)__shfl((int)(unsigned)(rem & 0xffffffffull), own, 64);
                 const unsigned hi = (unsigned)__shfl((int)(unsigned)(rem >> 32), own, 64);
                 const unsigned long long w = ((unsigned long long)hi << 32) | lo;
                 if ((w >> ti) & 1ull) continue;
-                const int ri = ord2[p0 + i];
-                if (lane == 0) kflag[ri] = 1;
-                const float4 pb = sbox[ri];
+                const int si = (int)(key[p0 + i] & kSlotMask);
+                if (lane == 0) kflag[si] = 1;
+                const float4 pb = cbox[si];
                 for (int t = ti; t < T; ++t) {
                     const int j = lane + 64 * t;
-                    if (j > i && j < n) {
-                        const float4 q = sbox[ord2[p0 + j]];
+                    if (j > i && j < len) {
+                        const float4 q = cbox[key[p0 + j] & kSlotMask];
                         const float v = yfs_iou_corners(pb.x, pb.y, pb.z, pb.w, q.x, q.y, q.z, q.w);
                         if (v > g.iou_thr) rem |= 1ull << t;
                     }
@@ -425,42 +465,44 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
             }
         }
     }
+    if (tid == 0) ctl[1] = 0;
     __syncthreads();
 
-    // ---- kept boxes, compacted in score order ----
-    int nk = 0;
-    for (int base = 0; base < K; base += kThreads) {
-        const int r = base + tid;
-        const bool f = r < K && kflag[r] != 0;
-        const unsigned long long bal = __ballot(f);
-        if (lane == 0) segs[wave] = __builtin_popcountll(bal);
-        __syncthreads();
-        int off = nk, tot = 0;
-#pragma unroll
-        for (int w = 0; w < kThreads / 64; ++w) {
-            const int cw = segs[w];
-            off += w < wave ? cw : 0;
-            tot += cw;
+    // ---- D: kept boxes back in (score desc, index) order: drop the class field, sort once more ----
+    for (int p0 = 0; p0 < ns; p0 += kThreads) {
+        const int p = p0 + tid;
+        bool f = false;
+        if (p < ns) {
+            const unsigned long long k = key[p];
+            f = p < K && kflag[k & kSlotMask] != 0;
+            key[p] = f ? (k & ((1ull << kClsShift) - 1ull)) : ~0ull;
         }
-        if (f) kept[off + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = sidx[r];
-        nk += tot;
-        __syncthreads();
+        const unsigned long long bal = __ballot(f);
+        if (lane == 0 && bal) atomicAdd(&ctl[1], __builtin_popcountll(bal));   // a count: order does not matter
     }
+    __syncthreads();
+    const int nk = ctl[1];
+    bitonic_sort(key, ns, tid);
 
-    // ---- D: outputs ----
     int32_t* kp = g.keep + n * (int64_t)A;
-    for (int i = tid; i < A; i += kThreads) kp[i] = i < nk ? kept[i] : -1;
+    for (int i = tid; i < A; i += kThreads) kp[i] = i < nk ? cidx[key[i] & kSlotMask] : -1;
     if (tid == 0) g.count[n] = nk;
 }
 
-size_t nms_lds_bytes(int cap, bool fused, int bpc, int D) {
-    size_t head = 28 * (size_t)cap + 16;
-    size_t tail = 28 * (size_t)cap;
+size_t nms_lds_bytes(int cap, int npow, bool fused, int bpc, int D) {
+    size_t head = 20 * (size_t)cap + 8 * (size_t)npow;
+    size_t tail = 8 * (size_t)cap;
     if (fused) {
         size_t rawb = (size_t)YFS_STAGE_FLOATS(bpc * D) * 4;
         if (rawb > tail) tail = rawb;
     }
     return head + tail;
+}
+
+int pow2_at_least(int v) {
+    int p = 2;
+    while (p < v) p <<= 1;
+    return p;
 }
 
 }  // namespace
@@ -566,9 +608,9 @@ YFS_API int yfs_nms_classwise_f32(const float* boxes, const float* score, const 
                 YFS_NMS_MAX_BOXES);
     NmsArgs g = {};
     g.boxes_in = (const float4*)boxes; g.score_in = score; g.cls_in = cls;
-    g.keep = keep; g.count = count; g.A = A; g.cap = (A + 63) & ~63;
+    g.keep = keep; g.count = count; g.A = A; g.cap = (A + 63) & ~63; g.npow = pow2_at_least(g.cap);
     g.score_thr = score_thr; g.iou_thr = iou_thr;
-    const size_t lds = nms_lds_bytes(g.cap, false, 0, 0);
+    const size_t lds = nms_lds_bytes(g.cap, g.npow, false, 0, 0);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)nms_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         YFS_REQUIRE(e == hipSuccess, YFS_ERR_LAUNCH, "yfs_nms_classwise_f32: cannot reserve %zu bytes of LDS", lds);
@@ -590,10 +632,13 @@ YFS_API int yfs_decode_nms_f32(const float* raw, int64_t N, int S, int A, int C,
     NmsArgs g = {};
     g.raw = raw; g.anchors = anchors; g.S = S; g.A_anch = A; g.C = C;
     g.boxes_out = (float4*)boxes; g.score_out = score; g.cls_out = cls;
-    g.keep = keep; g.count = count; g.A = (int)per; g.cap = ((int)per + 63) & ~63;
+    g.keep = keep; g.count = count; g.A = (int)per; g.cap = ((int)per + 63) & ~63; g.npow = pow2_at_least(g.cap);
+    // 128-box staging chunks: at S=13, A=5, C=20 the workgroup then needs 39 KiB of LDS and four fit on a CU, so a
+    // batch of 1024 images is one resident round instead of 1.33 rounds of three per CU
     g.bpc = pick_boxes_per_block(5 + C);
+    if (g.bpc > 128) g.bpc = 128;
     g.score_thr = score_thr; g.iou_thr = iou_thr;
-    const size_t lds = nms_lds_bytes(g.cap, true, g.bpc, 5 + C);
+    const size_t lds = nms_lds_bytes(g.cap, g.npow, true, g.bpc, 5 + C);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)nms_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         YFS_REQUIRE(e == hipSuccess, YFS_ERR_LAUNCH, "yfs_decode_nms_f32: cannot reserve %zu bytes of LDS", lds);
