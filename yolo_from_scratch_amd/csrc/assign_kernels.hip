@@ -39,7 +39,9 @@ __global__ void __launch_bounds__(kThreads) assign_v2_kernel(const float* __rest
     const int per = S * S * A;
     // carve: per gt 10 floats: slot(int), tx, ty, tw, th, cls, cx, cy, w, h
     float* ginfo = lds;
-    float* tstage = lds + ((10 * G + 3) & ~3);
+    int* vlist = reinterpret_cast<int*>(lds + ((10 * G + 3) & ~3));     // indices of the valid gts, ascending
+    float* tstage = lds + ((10 * G + 3) & ~3) + ((G + 3) & ~3);
+    __shared__ int nvalid;
     const float* g = gt + n * (int64_t)G * 5;
     const float fS = (float)S;
     for (int k = tid; k < G; k += kThreads) {
@@ -72,9 +74,25 @@ __global__ void __launch_bounds__(kThreads) assign_v2_kernel(const float* __rest
         o[6] = cx; o[7] = cy; o[8] = w; o[9] = h;
     }
     __syncthreads();
+    // The gt list is padded to G rows and typically holds 1-3 real boxes: compact the valid indices (in index
+    // order, so "lowest gt index wins" is unchanged) and let the per-slot loops below run over those only.
+    if (tid < 64) {
+        int cnt = 0;
+        for (int base = 0; base < G; base += 64) {
+            const int k = base + tid;
+            const bool valid = k < G && __float_as_int(ginfo[10 * k]) >= 0;
+            const unsigned long long bal = __ballot(valid);
+            if (valid) vlist[cnt + __builtin_popcountll(bal & ((1ull << tid) - 1ull))] = k;
+            cnt += __builtin_popcountll(bal);
+        }
+        if (tid == 0) nvalid = cnt;
+    }
+    __syncthreads();
+    const int V = nvalid;
     for (int c = tid; c < per; c += kThreads) {
         int owner = -1;
-        for (int k = 0; k < G; ++k) {
+        for (int v = 0; v < V; ++v) {
+            const int k = vlist[v];
             if (__float_as_int(ginfo[10 * k]) == c) { owner = k; break; }
         }
         float* t = tstage + 5 * c;
@@ -88,9 +106,8 @@ __global__ void __launch_bounds__(kThreads) assign_v2_kernel(const float* __rest
         if (pred_boxes) {
             const float4 p = pred_boxes[n * per + c];
             float best = 0.0f;
-            for (int k = 0; k < G; ++k) {
-                const float* o = ginfo + 10 * k;
-                if (__float_as_int(o[0]) < 0) continue;
+            for (int vi = 0; vi < V; ++vi) {
+                const float* o = ginfo + 10 * vlist[vi];
                 const float v = yfs_iou_xywh(p.x, p.y, p.z, p.w, o[6], o[7], o[8], o[9]);
                 if (v > best) best = v;
             }
@@ -112,7 +129,7 @@ YFS_API int yfs_assign_targets_v2_f32(const float* gt, int64_t N, int G, int S, 
                 "yfs_assign_targets_v2_f32: null pointer");
     YFS_REQUIRE(N > 0 && G > 0 && S > 0 && A > 0, YFS_ERR_INVALID_ARG,
                 "yfs_assign_targets_v2_f32: bad shape N=%lld G=%d S=%d A=%d", (long long)N, G, S, A);
-    const size_t lds = ((size_t)((10 * G + 3) & ~3) + (size_t)S * S * A * 5 + 8) * sizeof(float);
+    const size_t lds = ((size_t)((10 * G + 3) & ~3) + (size_t)((G + 3) & ~3) + (size_t)S * S * A * 5 + 8) * sizeof(float);
     YFS_REQUIRE(lds <= 150 * 1024, YFS_ERR_UNSUPPORTED,
                 "yfs_assign_targets_v2_f32: S=%d A=%d G=%d needs %zu bytes of LDS (max 153600)", S, A, G, lds);
     if (lds > 64 * 1024) {
