@@ -19,6 +19,16 @@ import torch
 import torch.distributed as dist
 
 
+_PRODUCERS = []
+
+
+def register_producer_stream(stream):
+    """Streams other than the current one on which gradient kernels are enqueued (model.py runs the weight
+    gradients on a side stream); a bucket's all-reduce waits for all of them."""
+    if stream not in _PRODUCERS:
+        _PRODUCERS.append(stream)
+
+
 class GradComm:
     def __init__(self, world_size=None, bucket_bytes=256 << 20, compress_bf16=False, group=None):
         self.group = group
@@ -88,10 +98,15 @@ class GradComm:
             dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
             chunk.mul_(1.0 / self.world)
             return
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
+        cur = torch.cuda.current_stream()
+        evs = []
+        for st in [cur] + [p for p in _PRODUCERS if p != cur and p.device == cur.device]:
+            ev = torch.cuda.Event()
+            ev.record(st)
+            evs.append(ev)
         with torch.cuda.stream(self.stream):
-            self.stream.wait_event(ev)
+            for ev in evs:
+                self.stream.wait_event(ev)
             if self.compress:
                 c = self._c16[: hi - lo]
                 c.copy_(chunk)

@@ -10,6 +10,8 @@ implicit-GEMM launch (conv + bias + LeakyReLU), and when ``feat`` is called as a
 pass runs as one chain in which each dgrad applies the previous block's LeakyReLU derivative in its
 epilogue and each pool backward does the same for the block feeding it.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -18,6 +20,7 @@ from . import _lib as L
 from . import conv_ops as co
 
 SLOPE = 0.1
+_TWO_STREAMS = os.environ.get("YFS_WGRAD_STREAM", "1") != "0"
 
 
 def _pool_fwd(x):
@@ -214,6 +217,19 @@ class HipMaxPool2d(nn.Module):
         return _PoolFn.apply(x)
 
 
+_SIDE = {}
+
+
+def _side_stream(device):
+    """Second HIP stream per device for the weight-gradient kernels of the backward chain."""
+    key = (device.type, device.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+        from . import dp
+        dp.register_producer_stream(_SIDE[key])
+    return _SIDE[key]
+
+
 class _BackboneFn(torch.autograd.Function):
     """All of ``feat`` as one autograd node: forward = chain of fused conv / pool launches; backward walks
     it in reverse with the LeakyReLU derivative folded into dgrad epilogues and pool backward."""
@@ -259,19 +275,38 @@ class _BackboneFn(torch.autograd.Function):
         g = co.nhwc(dy, torch.bfloat16)
         if stages[last] != "P":
             g = co.leaky_bwd(g, acts[last], SLOPE)
+        # dz of a block feeds two independent kernels: its weight gradient and the next dgrad.  The weight
+        # gradients run on a second stream so that the tails of one kernel family (partly filled last rounds,
+        # the small split-K reductions) overlap the other instead of leaving CUs idle.
+        main = torch.cuda.current_stream()
+        side = _side_stream(dy.device) if _TWO_STREAMS else None
         for i in range(last, -1, -1):
             if stages[i] == "P":
                 g = _pool_bwd_idx(acts[i], gins[i], g, fuse_leaky=(i > 0 and stages[i - 1] != "P"))
                 continue
             plan = plans[i]
             pi -= 2
-            dw, db = plan.wgrad(gins[i], g, ctx.params[pi], ctx.params[pi + 1])
+            if side is not None:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)
+                    g.record_stream(side)
+                    gins[i].record_stream(side)
+                    dw, db = plan.wgrad(gins[i], g, ctx.params[pi], ctx.params[pi + 1])
+                    for t in (dw, db):
+                        if t is not None:
+                            t.record_stream(main)
+            else:
+                dw, db = plan.wgrad(gins[i], g, ctx.params[pi], ctx.params[pi + 1])
             grads[pi], grads[pi + 1] = dw, db
             if i == 0:
                 break
             prev_is_conv = stages[i - 1] != "P"
             g = co.conv_dgrad(g, plan.wt16, acts[i - 1].shape[2:], plan.stride,
                               x_act=acts[i - 1] if prev_is_conv else None, slope=SLOPE)
+        if side is not None:
+            main.wait_stream(side)
         ctx.acts = ctx.gins = ctx.plans = ctx.params = None
         return (None, None) + tuple(grads)
 
