@@ -211,3 +211,36 @@ def test_config1_forward_loss_decode_nms_vs_cpu_oracle():
     keep_o, cnt_o = oracle.nms(b.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy(), 0.05, 0.5)
     np.testing.assert_array_equal(cnt.cpu().numpy(), cnt_o)
     np.testing.assert_array_equal(keep.cpu().numpy(), keep_o)
+
+
+def test_fit_epoch_loop_checkpoint_and_log(tmp_path):
+    """The reference's epoch loop (yolo_toy_regressor_torch.py:397-432): LR schedule per epoch, best-only
+    checkpoint with the reference's key names (dense NCHW tensors that plain torch modules load), quality log
+    lines in utils/logger_quality.py's format, best weights reloaded at the end."""
+    import json
+    from yolo_from_scratch_amd import run
+    torch.manual_seed(0)
+    net = ym.YoloRegressorModel(head_out=4, image_size=64).to(DEV)
+    xs = torch.rand(16, 3, 64, 64)
+    ys = torch.rand(16, 4) * 0.5 + 0.25
+    loader = [(xs[i:i + 8], ys[i:i + 8]) for i in (0, 8)]
+    opt = yt.FlatSGD(net.parameters(), lr=1e-3, momentum=0.9, weight_decay=5e-4)
+    best = tmp_path / "best_val_iou.pt"
+    log = tmp_path / "q.log"
+    hist = run.fit(net, loader, loader, DEV, opt, y.MSELoss(), total_epochs=3, warmup=2, patience=15, best_path=best,
+                   log_path=log, side_dir=tmp_path, verbose=False)
+    assert hist["epoch"] == [1, 2, 3]
+    assert hist["lr"] == [yt.yolo_v1_lr_schedule(e, total_epochs=3, warmup=2) for e in range(3)]
+    recs = [json.loads(line) for line in log.read_text().splitlines()]
+    assert [r["epoch"] for r in recs if r["tag"] == "QUALITY"] == [1, 2, 3]
+    assert any(r["tag"] == "QUALITY_BEST" for r in recs)
+    sd = torch.load(best, weights_only=True)
+    assert list(sd.keys()) == list(net.state_dict().keys())
+    assert all(v.is_contiguous() and v.device.type == "cpu" for v in sd.values())
+    conv = nn.Conv2d(3, 192, 7, stride=2, padding=3)                      # the reference's own module type
+    conv.load_state_dict({"weight": sd["feat.0.0.weight"], "bias": sd["feat.0.0.bias"]})
+    # the model now holds the best epoch's weights, and the optimiser's bf16 shadow follows them
+    for k, v in net.state_dict().items():
+        assert torch.equal(v.cpu().contiguous(), sd[k]), k
+    w = net.feat[2][0].weight
+    assert torch.equal(yt.bf16_shadow(w).float(), w.detach().to(torch.bfloat16).float())
