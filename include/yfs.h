@@ -183,6 +183,12 @@ int yfs_sumsq_f32(const float *g, int64_t n, float *sumsq_out, void *workspace, 
 int yfs_sgd_step_f32(float *p, const float *g, float *buf, int64_t n, const float *sumsq, float max_norm,
                      float lr, float momentum, float weight_decay, int first_step, void *p_bf16, void *stream);
 
+/* k-means anchor clustering, assignment step (reference: README.md:56 names the feature; nearest code is the k=1
+ * median prior estimate_size_priors, practice/yolo_toy_regressor_3_torch.py:278-286).  wh [n,2], anchors [k,2] in
+ * the same units, k <= 64 -> assign [n] = argmax_j shape-IoU (ties -> lowest j), best_iou [n] (may be NULL). */
+int yfs_anchor_assign_f32(const float *wh, int64_t n, const float *anchors, int k, int32_t *assign, float *best_iou,
+                          void *stream);
+
 /* Measurement aid, no reference counterpart: enqueue a register-only bf16 MFMA loop (blocks x 4 waves x iters x
  * 16 MFMAs of 16x16x32) and return the FLOPs it performs in *flop_out; the caller times it.  scratch: >= 4 bytes of
  * device memory (never written in practice).  bench.py prints the resulting rate next to the vendor peak. */

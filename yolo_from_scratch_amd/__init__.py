@@ -6,3 +6,5 @@ from .boxes import (iou_xywh_torch, iou_xywh_rows, iou_variant, pairwise_iou, de
                     decode_grid, class_scores, decode_v1, nms, decode_nms, DecodeNms)
 from .loss import YoloV1Loss, MSELoss  # noqa: F401
 from .assign import assign_targets_v2, VOC_ANCHORS  # noqa: F401
+from .anchors import estimate_size_priors, kmeans_anchors, anchor_assign  # noqa: F401
+from .metrics import mean_average_precision  # noqa: F401

@@ -122,6 +122,47 @@ __global__ void __launch_bounds__(kThreads) assign_v2_kernel(const float* __rest
 
 }  // namespace
 
+// k-means anchor clustering, assignment step (README.md:56 "k-means or VOC defaults"; SPEC.md §6): every box
+// (w, h) goes to the anchor with the highest shape IoU (both placed at the origin), ties -> lowest anchor.
+namespace {
+constexpr int kMaxAnchors = 64;
+__global__ void __launch_bounds__(kThreads) anchor_assign_kernel(const float2* __restrict__ wh, int64_t n,
+                                                                 const float* __restrict__ anchors, int k,
+                                                                 int32_t* __restrict__ assign, float* __restrict__ best_iou) {
+    __shared__ float a[2 * kMaxAnchors];
+    for (int i = threadIdx.x; i < 2 * k; i += kThreads) a[i] = anchors[i];
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+        const float2 b = wh[i];
+        int best = 0;
+        float bi = -1.0f;
+        for (int j = 0; j < k; ++j) {
+            const float aw = a[2 * j], ah = a[2 * j + 1];
+            const float inter = fminf(b.x, aw) * fminf(b.y, ah);
+            const float uni = b.x * b.y + aw * ah - inter;
+            const float iou = uni > 0.0f ? inter / uni : 0.0f;
+            if (iou > bi) { bi = iou; best = j; }
+        }
+        assign[i] = best;
+        if (best_iou) best_iou[i] = bi;
+    }
+}
+}  // namespace
+
+YFS_API int yfs_anchor_assign_f32(const float* wh, int64_t n, const float* anchors, int k, int32_t* assign, float* best_iou,
+                                  void* stream) {
+    YFS_REQUIRE(wh && anchors && assign, YFS_ERR_INVALID_ARG, "yfs_anchor_assign_f32: null pointer");
+    YFS_REQUIRE(n > 0 && k > 0 && k <= kMaxAnchors, YFS_ERR_INVALID_ARG, "yfs_anchor_assign_f32: bad shape n=%lld k=%d (k <= %d)",
+                (long long)n, k, kMaxAnchors);
+    YFS_REQUIRE((reinterpret_cast<uintptr_t>(wh) & 7) == 0, YFS_ERR_INVALID_ARG, "yfs_anchor_assign_f32: wh must be 8-byte aligned");
+    long long blk = yfs_cdiv(n, kThreads);
+    if (blk > 4096) blk = 4096;
+    anchor_assign_kernel<<<dim3((unsigned)blk), dim3(kThreads), 0, (hipStream_t)stream>>>((const float2*)wh, n, anchors, k, assign,
+                                                                                      best_iou);
+    YFS_CHECK_LAUNCH("anchor_assign_kernel");
+    return YFS_OK;
+}
+
 YFS_API int yfs_assign_targets_v2_f32(const float* gt, int64_t N, int G, int S, int A, const float* anchors,
                                       const float* pred_boxes, float ignore_thr, uint8_t* obj_mask,
                                       uint8_t* ignore_mask, float* targets, void* stream) {
