@@ -169,6 +169,16 @@ int yfs_maxpool2_bwd_bf16(const void *x, const void *dy, void *dx, int64_t N, in
 int yfs_maxpool2_fwd_idx_bf16(const void *x, void *y, void *idx, int64_t N, int H, int W, int C, void *stream);
 int yfs_maxpool2_bwd_idx_bf16(const void *y, const void *idx, const void *dy, void *dx, int64_t N, int H, int W,
                               int C, int fuse_leaky, float slope, void *stream);
+/* Conv2D block followed by pool() (:220-221, :224-225, :231-232, :245-246) in one launch: bias + LeakyReLU +
+ * 2x2/2 max pool in the GEMM epilogue.  Writes only the pooled activation y_pooled [N,OH/2,OW/2,Cout] and the
+ * window positions pool_idx (layout of yfs_maxpool2_fwd_idx_bf16); bit-identical to yfs_conv2d_fwd_bf16 followed
+ * by yfs_maxpool2_fwd_idx_bf16.  The full-resolution activation is never materialised (its only reader, the pool
+ * backward, works from y_pooled and pool_idx).  OH, OW must be even. */
+int yfs_conv2d_fwd_pool_bf16(const void *x, const void *w, const float *bias, void *y_pooled, void *pool_idx,
+                             int64_t N, int H, int W, int Cin, int Cout, int K, int stride, float slope,
+                             void *stream);
+int yfs_conv2d_stem_fwd_pool_bf16(const void *xs, const void *w2, const float *bias, void *y_pooled, void *pool_idx,
+                                  int64_t N, int Hs, int Ws, int OH, int OW, int Cout, float slope, void *stream);
 
 /* clip_grad_norm_ + SGD(momentum, weight_decay)  yolo_toy_regressor_torch.py:331-335, :378-381 on flat
  * fp32 arenas (all parameters / gradients / momentum buffers live in one allocation each).

@@ -175,3 +175,37 @@ def test_maxpool_both_paths_vs_oracle(n, c, hw, fuse):
         scale = np.where(xb.float().numpy() > 0, 1.0, 0.1).astype(np.float32)
         dx_ref = (torch.from_numpy(dx_ref) * torch.from_numpy(scale)).to(torch.bfloat16).float().numpy()
     np.testing.assert_array_equal(dx1.permute(0, 2, 3, 1).float().cpu().numpy(), dx_ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,cin,cout,k,hw", [(2, 64, 128, 3, 12), (1, 128, 192, 3, 10), (3, 64, 64, 1, 8), (2, 192, 256, 3, 16),
+                                             (64, 64, 256, 3, 64)])
+def test_conv_fwd_pool_fused_is_bit_identical(n, cin, cout, k, hw):
+    """Conv2D block + pool() in one launch (pool in the GEMM epilogue, rows enumerated window-major) must equal the
+    block followed by the pool kernel bit for bit: pooled values and saved window positions.  The shapes hit the
+    128x128, 128x192, 128x64 and 256x256 tiles."""
+    from yolo_from_scratch_amd import model as ym
+    x, w, b = _case(n, cin, cout, k, hw, seed=cin + cout + k + hw)
+    xd = co.nhwc(x.to(DEV), torch.bfloat16)
+    w16, _ = co.weight_prep(co.nhwc(w.to(DEV)), want_wt16=False)
+    bd = b.to(DEV)
+    y_full = co.conv_fwd(xd, w16, bd, 1)
+    y_ref, idx_ref = ym._pool_fwd_idx(y_full)
+    y, idx = co.conv_fwd_pool(xd, w16, bd, 1)
+    assert torch.equal(y, y_ref)
+    assert torch.equal(idx, idx_ref)
+
+
+@pytest.mark.gpu
+def test_stem_fwd_pool_fused_is_bit_identical():
+    from yolo_from_scratch_amd import model as ym
+    torch.manual_seed(3)
+    x = torch.rand(2, 3, 64, 64)
+    w = _bf(torch.randn(192, 3, 7, 7) * 0.05)
+    b = torch.randn(192)
+    xs = co.stem_space_to_depth(x.to(DEV))
+    w2 = co.stem_weight(co.nhwc(w.to(DEV)))
+    oh, ow, _, _ = co.stem_geometry(64, 64)
+    y_ref, idx_ref = ym._pool_fwd_idx(co.stem_fwd(xs, w2, b.to(DEV), oh, ow))
+    y, idx = co.stem_fwd_pool(xs, w2, b.to(DEV), oh, ow)
+    assert torch.equal(y, y_ref) and torch.equal(idx, idx_ref)

@@ -56,6 +56,24 @@ def weight_prep(w, want_w16=True, want_wt16=True):
     return w16, wt16
 
 
+def conv_fwd_pool(x, w16, bias, stride=1, slope=0.1):
+    """max_pool2x2(leaky(conv(x, w) + bias)) in one launch -> (pooled y [N,Cout,OH/2,OW/2] bf16, idx int16): the pool
+    runs in the GEMM epilogue and the full-resolution activation is never written."""
+    L.require_cuda(x, w16, bias)
+    x = nhwc(x, torch.bfloat16)
+    n, cin, h, w = x.shape
+    cout, cin2, k, _ = w16.shape
+    if cin2 != cin:
+        raise L.YfsError(f"conv_fwd_pool: input has {cin} channels, weight expects {cin2}")
+    oh, ow = out_hw(h, w, k, stride)
+    y = _empty_nhwc(n, cout, oh // 2, ow // 2, x.device)
+    idx = torch.empty(n * (oh // 2) * (ow // 2) * (cout // 8), device=x.device, dtype=torch.int16)
+    L.check(L.lib().yfs_conv2d_fwd_pool_bf16(L.ptr(x), L.ptr(w16), L.ptr(bias), L.ptr(y), L.ptr(idx), L.i64(n), L.c_int(h),
+                                             L.c_int(w), L.c_int(cin), L.c_int(cout), L.c_int(k), L.c_int(stride),
+                                             L.c_float(slope), L.stream()), "yfs_conv2d_fwd_pool_bf16")
+    return y, idx
+
+
 class _WeightDesc(ctypes.Structure):       # include/yfs.h: yfs_weight_desc
     _fields_ = [("w", ctypes.c_void_p), ("w_bf16", ctypes.c_void_p), ("wt_bf16", ctypes.c_void_p),
                 ("Cout", ctypes.c_int), ("K", ctypes.c_int), ("Cin", ctypes.c_int), ("w_is_bf16", ctypes.c_int)]
@@ -244,6 +262,18 @@ def stem_fwd(xs, w2, bias, oh, ow, slope=0.1):
                                              L.c_int(oh), L.c_int(ow), L.c_int(cout), L.c_float(slope), L.stream()),
             "yfs_conv2d_stem_fwd_bf16")
     return y
+
+
+def stem_fwd_pool(xs, w2, bias, oh, ow, slope=0.1):
+    """Stem conv + LeakyReLU + 2x2 max pool in one launch -> (pooled y, idx); see conv_fwd_pool."""
+    n, _, hs, ws = xs.shape
+    cout = w2.shape[0]
+    y = _empty_nhwc(n, cout, oh // 2, ow // 2, xs.device)
+    idx = torch.empty(n * (oh // 2) * (ow // 2) * (cout // 8), device=xs.device, dtype=torch.int16)
+    L.check(L.lib().yfs_conv2d_stem_fwd_pool_bf16(L.ptr(xs), L.ptr(w2), L.ptr(bias), L.ptr(y), L.ptr(idx), L.i64(n),
+                                                  L.c_int(hs), L.c_int(ws), L.c_int(oh), L.c_int(ow), L.c_int(cout),
+                                                  L.c_float(slope), L.stream()), "yfs_conv2d_stem_fwd_pool_bf16")
+    return y, idx
 
 
 def stem_wgrad(xs, dz):

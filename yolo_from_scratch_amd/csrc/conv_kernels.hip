@@ -43,13 +43,14 @@ __device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned o
 constexpr int kThreads = 256;
 constexpr int BK = 64;   // reduction depth per LDS tile (128 B rows)
 
-enum { EPI_BIAS_LEAKY = 0, EPI_MASK = 1, EPI_NONE = 2 };
+enum { EPI_BIAS_LEAKY = 0, EPI_MASK = 1, EPI_NONE = 2, EPI_POOL = 3 };
 
 struct IgemmArgs {
     const bf16_t* x;      // [N,H,W,C]
     const bf16_t* w;      // [NOUT][taps][C]
     const float* bias;    // [NOUT]            (EPI_BIAS_LEAKY)
     const bf16_t* act;    // [M][NOUT]         (EPI_MASK: multiply by act > 0 ? 1 : slope)
+    unsigned short* pool_idx;   // EPI_POOL: [M/4][NOUT/8] eight 2-bit window positions each; out is then [M/4][NOUT]
     bf16_t* out;          // [M][NOUT]
     int N, H, W, C;
     int OH, OW, NOUT;
@@ -146,9 +147,22 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) igemm_kernel(IgemmArgs g) {
     for (int i = 0; i < RA; ++i) {
         const int m = m0 + (wave * RA + i) * 8 + (lane >> 3);
         if (m < Mc) {
-            const int n = m / (OHc * OWc);
-            const int rem = m - n * (OHc * OWc);
-            const int oh = rem / OWc, ow = rem - oh * OWc;
+            int n, oh, ow;
+            if (EPI == EPI_POOL) {
+                // pool-fused forward: rows are enumerated window-major, m = 4 * (pooled pixel) + (dy * 2 + dx), so
+                // the four pixels of every 2x2 pooling window are four consecutive rows of one tile
+                const int q = m >> 2, sub = m & 3, PW = OWc >> 1, PHW = (OHc >> 1) * PW;
+                n = q / PHW;
+                const int r = q - n * PHW;
+                const int py = r / PW, px = r - py * PW;
+                oh = 2 * py + (sub >> 1);
+                ow = 2 * px + (sub & 1);
+            } else {
+                n = m / (OHc * OWc);
+                const int rem = m - n * (OHc * OWc);
+                oh = rem / OWc;
+                ow = rem - oh * OWc;
+            }
             bh[i] = SUB ? oh : oh * g.s_mul - g.pad;   // SUB: class-grid coordinates; the tap supplies the shift
             bw[i] = SUB ? ow : ow * g.s_mul - g.pad;
             rowbyte[i] = (unsigned)(((long long)(n * g.H + bh[i]) * g.W + bw[i]) * g.PS * 2) + chunk * 16;
@@ -253,7 +267,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) igemm_kernel(IgemmArgs g) {
     int ec = (tid % TPR) * 8;
     const int er = tid / TPR;
     float bv[8];
-    if (EPI == EPI_BIAS_LEAKY && EVEN) {
+    if (EPI == EPI_BIAS_LEAKY && EVEN) {   // (EPI_POOL loads its bias per item below)
 #pragma unroll
         for (int j = 0; j < 8; ++j) bv[j] = g.bias[n0 + ec + j];
     }
@@ -269,6 +283,40 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) igemm_kernel(IgemmArgs g) {
                 *reinterpret_cast<f32x4*>(smem + (prow - pass * PR + frow) * EPI_STRIDE + ch * 4) = acc[a][b];
             }
         __syncthreads();
+        if (EPI == EPI_POOL) {
+            // bias + LeakyReLU + one rounding to bf16 for the four pixels of a window, then the 2x2 max over the
+            // ROUNDED values with "first maximum wins" — bit-identical to conv forward followed by the pool kernel;
+            // only the pooled tensor and the 2-bit positions leave the CU (the full-resolution activation has no
+            // reader: pool backward works from the pooled output and the positions).
+            for (int item = tid; item < (PR / 4) * TPR; item += NT) {
+                const int w = item / TPR, c8 = item - w * TPR;
+                const int q = ((m0 + pass * PR) >> 2) + w;
+                if (q * 4 >= Mc) continue;
+                float bvp[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bvp[j] = g.bias[n0 + c8 * 8 + j];
+                bf16x8 best;
+                unsigned packed = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned char* rp = smem + (4 * w + k) * EPI_STRIDE + c8 * 32;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(rp);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(rp + 16);
+                    const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float t = v[j] + bvp[j];
+                        const bf16_t yv = (bf16_t)(t > 0.0f ? t : t * g.slope);
+                        if (k == 0 || (float)yv > (float)best[j]) {
+                            best[j] = yv;
+                            packed = (packed & ~(3u << (2 * j))) | ((unsigned)k << (2 * j));
+                        }
+                    }
+                }
+                *reinterpret_cast<bf16x8*>(g.out + (long long)q * g.NOUT + n0 + c8 * 8) = best;
+                g.pool_idx[(long long)q * (g.NOUT / 8) + (n0 >> 3) + c8] = (unsigned short)packed;
+            }
+        } else {
 #pragma unroll
         for (int p = 0; p < SWEEPS; ++p) {
             int row = er + p * RPP;
@@ -309,6 +357,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) igemm_kernel(IgemmArgs g) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) ov[j] = (bf16_t)v[j];
             *reinterpret_cast<bf16x8*>(g.out + o) = ov;
+        }
         }
         if (pass + 1 < EPASS) __syncthreads();
     }
@@ -407,6 +456,24 @@ YFS_API int yfs_conv2d_fwd_bf16(const void* x, const void* w, const float* bias,
     g.M = (int)(N * g.OH * g.OW);
     g.xbytes = (unsigned)(N * H * W * Cin * 2); g.wbytes = (unsigned)((int64_t)Cout * K * K * Cin * 2);
     return dispatch_igemm<EPI_BIAS_LEAKY, false>(g, (hipStream_t)stream, "yfs_conv2d_fwd_bf16");
+}
+
+YFS_API int yfs_conv2d_fwd_pool_bf16(const void* x, const void* w, const float* bias, void* y_pooled, void* pool_idx, int64_t N,
+                                     int H, int W, int Cin, int Cout, int K, int stride, float slope, void* stream) {
+    YFS_REQUIRE(x && w && bias && y_pooled && pool_idx, YFS_ERR_INVALID_ARG, "yfs_conv2d_fwd_pool_bf16: null pointer");
+    int rc = check_conv_shape("yfs_conv2d_fwd_pool_bf16", N, H, W, Cin, Cout, K, stride);
+    if (rc) return rc;
+    const int pad = K / 2;
+    IgemmArgs g = {};
+    g.x = (const bf16_t*)x; g.w = (const bf16_t*)w; g.bias = bias; g.out = (bf16_t*)y_pooled; g.pool_idx = (unsigned short*)pool_idx;
+    g.N = (int)N; g.H = H; g.W = W; g.C = Cin;
+    g.OH = (H + 2 * pad - K) / stride + 1; g.OW = (W + 2 * pad - K) / stride + 1; g.NOUT = Cout;
+    YFS_REQUIRE(g.OH % 2 == 0 && g.OW % 2 == 0, YFS_ERR_UNSUPPORTED,
+                "yfs_conv2d_fwd_pool_bf16: conv output %dx%d must be even for the fused 2x2 pool", g.OH, g.OW);
+    g.KH = g.KW = K; g.PS = Cin; g.s_mul = stride; g.pad = pad; g.slope = slope;
+    g.M = (int)(N * g.OH * g.OW);
+    g.xbytes = (unsigned)(N * H * W * Cin * 2); g.wbytes = (unsigned)((int64_t)Cout * K * K * Cin * 2);
+    return dispatch_igemm<EPI_POOL, false>(g, (hipStream_t)stream, "yfs_conv2d_fwd_pool_bf16");
 }
 
 YFS_API int yfs_conv2d_dgrad_bf16(const void* dz, const void* wt, const void* x_act, void* dx, int64_t N, int H, int W,
@@ -935,6 +1002,22 @@ YFS_API int yfs_conv2d_stem_fwd_bf16(const void* xs, const void* w2, const float
     g.M = (int)(N * OH * OW);
     g.xbytes = (unsigned)(N * Hs * Ws * kStemC * 2); g.wbytes = (unsigned)((int64_t)Cout * kStemKH * 64 * 2);
     return dispatch_igemm<EPI_BIAS_LEAKY, false>(g, (hipStream_t)stream, "yfs_conv2d_stem_fwd_bf16");
+}
+
+YFS_API int yfs_conv2d_stem_fwd_pool_bf16(const void* xs, const void* w2, const float* bias, void* y_pooled, void* pool_idx,
+                                          int64_t N, int Hs, int Ws, int OH, int OW, int Cout, float slope, void* stream) {
+    YFS_REQUIRE(xs && w2 && bias && y_pooled && pool_idx, YFS_ERR_INVALID_ARG, "yfs_conv2d_stem_fwd_pool_bf16: null pointer");
+    int rc = stem_check("yfs_conv2d_stem_fwd_pool_bf16", N, Hs, Ws, OH, OW, Cout);
+    if (rc) return rc;
+    YFS_REQUIRE(OH % 2 == 0 && OW % 2 == 0, YFS_ERR_UNSUPPORTED,
+                "yfs_conv2d_stem_fwd_pool_bf16: conv output %dx%d must be even for the fused 2x2 pool", OH, OW);
+    IgemmArgs g = {};
+    g.x = (const bf16_t*)xs; g.w = (const bf16_t*)w2; g.bias = bias; g.out = (bf16_t*)y_pooled; g.pool_idx = (unsigned short*)pool_idx;
+    g.N = (int)N; g.H = Hs; g.W = Ws; g.C = 64; g.PS = kStemC; g.OH = OH; g.OW = OW; g.NOUT = Cout;
+    g.KH = kStemKH; g.KW = 1; g.s_mul = 1; g.pad = 0; g.slope = slope;
+    g.M = (int)(N * OH * OW);
+    g.xbytes = (unsigned)(N * Hs * Ws * kStemC * 2); g.wbytes = (unsigned)((int64_t)Cout * kStemKH * 64 * 2);
+    return dispatch_igemm<EPI_POOL, false>(g, (hipStream_t)stream, "yfs_conv2d_stem_fwd_pool_bf16");
 }
 
 YFS_API size_t yfs_conv2d_stem_wgrad_workspace_bytes(int64_t N, int OH, int OW, int Cout) {

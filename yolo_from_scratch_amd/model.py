@@ -21,6 +21,7 @@ from . import conv_ops as co
 
 SLOPE = 0.1
 _TWO_STREAMS = os.environ.get("YFS_WGRAD_STREAM", "1") != "0"
+_FUSE_POOL = os.environ.get("YFS_FUSE_POOL", "1") != "0"
 
 
 def _pool_fwd(x):
@@ -100,6 +101,21 @@ class _ConvPlan:
             return xs, co.stem_fwd(xs, self.w16, self.bias, oh, ow, SLOPE)
         x = co.nhwc(x, torch.bfloat16)
         return x, co.conv_fwd(x, self.w16, self.bias, self.stride, SLOPE)
+
+    def forward_pool(self, x):
+        """Block + the 2x2 max pool that follows it, fused.  Returns (gemm_input, pooled y, idx)."""
+        if self.stem:
+            xs = co.stem_space_to_depth(x)
+            oh, ow, _, _ = co.stem_geometry(x.shape[2], x.shape[3])
+            return (xs,) + co.stem_fwd_pool(xs, self.w16, self.bias, oh, ow, SLOPE)
+        x = co.nhwc(x, torch.bfloat16)
+        return (x,) + co.conv_fwd_pool(x, self.w16, self.bias, self.stride, SLOPE)
+
+    def out_hw(self, h, w):
+        if self.stem:
+            oh, ow, _, _ = co.stem_geometry(h, w)
+            return oh, ow
+        return co.out_hw(h, w, self.k, self.stride)
 
     def wgrad(self, gemm_in, dz, weight, bias):
         """Weight / bias gradients: written into the parameters' gradient sinks when they have one (returns
@@ -244,19 +260,27 @@ class _BackboneFn(torch.autograd.Function):
         todo = [(params[2 * j], convs[j] > 0) for j in range(len(convs)) if params[2 * j].shape[1] % 64 == 0]
         prepared = iter(_ConvPlan.prepare(todo))
         pi = 0
-        for st in stages:
+        fused_idx = None
+        for si, st in enumerate(stages):
             if st == "P":
-                h, idx = _pool_fwd_idx(h)
+                if fused_idx is not None:         # the block before it already pooled in its epilogue
+                    idx, fused_idx = fused_idx, None
+                else:
+                    h, idx = _pool_fwd_idx(h)
                 plans.append(None)
                 gins.append(idx)          # a pool's backward needs its output and these 2-bit positions only
                 if acts:
-                    acts[-1] = None       # ... so the full-resolution block output before it can be freed now
+                    acts[-1] = None       # ... so the full-resolution block output before it is not kept
             else:
                 w, b = params[pi], params[pi + 1]
                 pi += 2
                 plan = _ConvPlan(w, b, st, need_wt=len(plans) > 0,
                                  prepared=next(prepared) if w.shape[1] % 64 == 0 else None)
-                gin, h = plan.forward(h)
+                oh, ow = plan.out_hw(h.shape[2], h.shape[3])
+                if _FUSE_POOL and si + 1 < len(stages) and stages[si + 1] == "P" and oh % 2 == 0 and ow % 2 == 0:
+                    gin, h, fused_idx = plan.forward_pool(h)   # h is already the pooled tensor
+                else:
+                    gin, h = plan.forward(h)
                 plans.append(plan)
                 gins.append(gin)
             acts.append(h)
