@@ -42,7 +42,7 @@ def main():
             flops = 2.0 * a.batch * oh * ow * cout * 147
             line = f"L0     3-> 192 k7 s2 448^2  GF={flops / 1e9:7.1f}"
             for op, fn in (("s2d", lambda: co.stem_space_to_depth(x)), ("fwd", lambda: co.stem_fwd(xs, w2, b, oh, ow)),
-                           ("wgrad", lambda: co.stem_wgrad(xs, dz))):
+                           ("fwdpool", lambda: co.stem_fwd_pool(xs, w2, b, oh, ow)), ("wgrad", lambda: co.stem_wgrad(xs, dz))):
                 if op != "s2d" and op not in tot:
                     continue
                 for _ in range(2):
@@ -68,7 +68,8 @@ def main():
         flops = 2.0 * a.batch * oh * ow * cout * cin * k * k
         line = f"L{li:<2d} {cin:4d}->{cout:4d} k{k} s{s} {hw:3d}^2  GF={flops / 1e9:7.1f}"
         for op in a.ops.split(","):
-            fn = {"fwd": lambda: co.conv_fwd(x, w16, b, s), "dgrad": lambda: co.conv_dgrad(dz, wt16, (hw, hw), s, x_act=x),
+            fn = {"fwd": lambda: co.conv_fwd(x, w16, b, s), "fwdpool": lambda: co.conv_fwd_pool(x, w16, b, s),
+                  "dgrad": lambda: co.conv_dgrad(dz, wt16, (hw, hw), s, x_act=x),
                   "wgrad": lambda: co.conv_wgrad(x, dz, k, s)}[op]
             for _ in range(2):
                 fn()
