@@ -436,7 +436,12 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
             unsigned long long removed = 0;
             for (int i = 0; i < len; ++i) {
                 if ((removed >> i) & 1ull) continue;
-                const float4 pb = cbox[__shfl(sj, i, 64)];
+                // i is wave-uniform: the kept box comes out of lane i's registers (v_readlane), not out of LDS
+                float4 pb;
+                pb.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.x), i));
+                pb.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.y), i));
+                pb.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.z), i));
+                pb.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.w), i));
                 const float v = yfs_iou_corners(pb.x, pb.y, pb.z, pb.w, q.x, q.y, q.z, q.w);
                 removed |= __ballot(mine && lane > i && v > g.iou_thr);
             }

@@ -373,6 +373,17 @@ class _LinearFn(torch.autograd.Function):
             w16 = weight.detach().to(torch.bfloat16)
         ctx.save_for_backward(x16, w16)
         ctx.wb, ctx.in_dtype = (weight, bias), x.dtype
+        m, k = x16.shape
+        n = w16.shape[0]
+        if k >= 8192 and m * n <= (1 << 20) and k % 64 == 0:
+            # fc.1 (64 x 4096 x 50176): a plain GEMM has 16 output tiles for 256 CUs and runs at a third of the
+            # rate the 411 MB weight stream allows; 8-way split-K as a batched GEMM with fp32 partials fills the
+            # chip (0.25 -> 0.09 ms) and is more accurate than bf16 accumulation across the whole K.
+            S = 8
+            xa = x16.view(m, S, k // S).transpose(0, 1)
+            wb = w16.view(n, S, k // S).permute(1, 2, 0)
+            y = torch.bmm(xa, wb, out_dtype=torch.float32).sum(0)
+            return (y + bias.detach().float()).to(torch.bfloat16)
         return torch.addmm(bias.detach().to(torch.bfloat16), x16, w16.t())
 
     @staticmethod
