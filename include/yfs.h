@@ -73,7 +73,7 @@ int yfs_decode_v1_f32(const float *pred, int64_t N, int S, int B, int C, float *
 
 /* Per-image class-wise greedy NMS.  No reference code (README.md:47, :68).
  * boxes [N,A,4] xywh; score [N,A]; cls [N,A] int32; keep [N,A] int32 kept indices in descending
- * score order, -1 padded; count [N] int32.  A <= YFS_NMS_MAX_BOXES. */
+ * score order, -1 padded; count [N] int32.  A <= YFS_NMS_MAX_BOXES; class ids in [0, 2^21). */
 #define YFS_NMS_MAX_BOXES 2048
 int yfs_nms_classwise_f32(const float *boxes, const float *score, const int32_t *cls, int64_t N, int A,
                           float score_thr, float iou_thr, int32_t *keep, int32_t *count, void *stream);
