@@ -171,6 +171,28 @@ def test_train_one_epoch_and_evaluate_surface():
     assert l1 < l0 and vl < l0 and 0.0 <= viou <= 1.0
 
 
+def test_load_state_dict_after_flat_sgd_two_linear_layers():
+    """The bf16 shadows are views of one arena and share its version counter: refreshing the second layer's
+    shadow (stale after load_state_dict) must not invalidate what the first layer saved for backward, and
+    the step must use the loaded weights."""
+    torch.manual_seed(3)
+    net = nn.Sequential(ym.HipLinear(64, 128), nn.LeakyReLU(0.1), ym.HipLinear(128, 32)).to(DEV)
+    opt = yt.FlatSGD(net.parameters(), lr=1e-2, momentum=0.0, weight_decay=0.0)
+    torch.manual_seed(4)
+    src = nn.Sequential(nn.Linear(64, 128), nn.LeakyReLU(0.1), nn.Linear(128, 32))
+    net.load_state_dict(src.state_dict())
+    x = torch.rand(16, 64)
+    opt.zero_grad()
+    out = net(x.to(DEV))
+    out.float().pow(2).mean().backward()
+    ref = src(_bf(x))
+    ref.pow(2).mean().backward()
+    assert _rel(out, ref) < 2e-2
+    assert _rel(net[0].weight.grad, src[0].weight.grad) < 3e-2
+    assert _rel(net[2].weight.grad, src[2].weight.grad) < 3e-2
+    opt.step()
+
+
 def test_config1_forward_loss_decode_nms_vs_cpu_oracle():
     """BASELINE configs[0]: synthetic 224x224, batch 8, S=7 B=2 C=20 — backbone +
     build-defined head -> composite loss -> decode -> class-wise NMS, every stage against the CPU oracle.

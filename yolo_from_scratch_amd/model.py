@@ -371,7 +371,11 @@ class _LinearFn(torch.autograd.Function):
         w16 = bf16_shadow(weight)
         if w16 is None:
             w16 = weight.detach().to(torch.bfloat16)
-        ctx.save_for_backward(x16, w16)
+        ctx.save_for_backward(x16)
+        # not through save_for_backward: every shadow is a view of one flat bf16 arena and shares its version
+        # counter, so refreshing ANOTHER parameter's shadow between forward and backward would trip the in-place
+        # check although this view's bytes are untouched
+        ctx.w16 = w16
         ctx.wb, ctx.in_dtype = (weight, bias), x.dtype
         m, k = x16.shape
         n = w16.shape[0]
@@ -389,7 +393,8 @@ class _LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         from .train import write_grad
-        x16, w16 = ctx.saved_tensors
+        (x16,) = ctx.saved_tensors
+        w16 = ctx.w16
         weight, bias = ctx.wb
         dy16 = dy.to(torch.bfloat16).contiguous()
         dx = torch.mm(dy16, w16).to(ctx.in_dtype) if ctx.needs_input_grad[0] else None
@@ -409,7 +414,7 @@ class _LinearFn(torch.autograd.Function):
                 return db
             sink.add_(db) if acc else sink.copy_(db)
         dw, db = write_grad(weight, put_w), write_grad(bias, put_b)
-        ctx.wb = None
+        ctx.wb = ctx.w16 = None
         return dx, dw, db
 
 
