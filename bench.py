@@ -70,7 +70,7 @@ class ConvTimers:
         self._orig = {}
         for key, name in (("conv_fwd", "conv_fwd"), ("conv_dgrad", "conv_dgrad"), ("conv_wgrad", "conv_wgrad"),
                           ("conv_fwd", "stem_fwd"), ("conv_wgrad", "stem_wgrad"), ("conv_fwd", "conv_fwd_pool"),
-                          ("conv_fwd", "stem_fwd_pool")):
+                          ("conv_fwd", "stem_fwd_pool"), ("conv_wgrad", "stem_wgrad_pool")):
             fn = getattr(co, name)
             self._orig[name] = fn
 

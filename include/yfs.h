@@ -156,6 +156,16 @@ int yfs_conv2d_stem_fwd_bf16(const void *xs, const void *w2, const float *bias, 
 size_t yfs_conv2d_stem_wgrad_workspace_bytes(int64_t N, int OH, int OW, int Cout);
 int yfs_conv2d_stem_wgrad_bf16(const void *xs, const void *dz, float *dw2, float *db, int64_t N, int Hs, int Ws, int OH,
                                int OW, int Cout, int accumulate, void *workspace, size_t workspace_bytes, void *stream);
+/* Backward of [stem conv (:220) -> LeakyReLU -> MaxPool2d(2,2) (:216)] with respect to the stem's weight and bias,
+ * taken from the POOLED side: dy_pooled [N,OH/2,OW/2,Cout] bf16 is the gradient of the pool's output, pool_idx
+ * the argmax record the fused forward wrote (yfs_conv2d_stem_fwd_pool_bf16), y_pooled the pooled activation
+ * (LeakyReLU derivative; NULL = dy_pooled already carries it).  Equals yfs_maxpool2_bwd_idx_bf16(fuse_leaky)
+ * followed by yfs_conv2d_stem_wgrad_bf16 (identical bf16 dz values; only the fp32 summation order over pixels
+ * differs), without writing and re-reading the full-resolution dz
+ * (3/4 zeros).  Workspace: yfs_conv2d_stem_wgrad_workspace_bytes. */
+int yfs_conv2d_stem_wgrad_pool_bf16(const void *xs, const void *dy_pooled, const void *pool_idx, const void *y_pooled,
+                                    float *dw2, float *db, int64_t N, int Hs, int Ws, int OH, int OW, int Cout,
+                                    float slope, int accumulate, void *workspace, size_t workspace_bytes, void *stream);
 
 /* MaxPool2d(2, 2)  yolo_toy_regressor_torch.py:216 on NHWC bf16.  H, W even. */
 int yfs_maxpool2_fwd_bf16(const void *x, void *y, int64_t N, int H, int W, int C, void *stream);

@@ -209,3 +209,27 @@ def test_stem_fwd_pool_fused_is_bit_identical():
     y_ref, idx_ref = ym._pool_fwd_idx(co.stem_fwd(xs, w2, b.to(DEV), oh, ow))
     y, idx = co.stem_fwd_pool(xs, w2, b.to(DEV), oh, ow)
     assert torch.equal(y, y_ref) and torch.equal(idx, idx_ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("leaky", [False, True])
+@pytest.mark.parametrize("n,hw,cout", [(2, 64, 192), (3, 36, 128), (1, 20, 64)])
+def test_stem_wgrad_from_pooled_side(n, hw, cout, leaky):
+    """Weight / bias gradient of [stem -> LeakyReLU -> pool] taken from (pooled gradient, argmax record, pooled
+    activation) == pool backward (with the LeakyReLU mask) followed by the ordinary stem wgrad.  The dz tiles hold
+    identical bf16 values; only the order in which pixels are summed differs (window-major), hence fp32 tolerance."""
+    from yolo_from_scratch_amd import model as ym
+    torch.manual_seed(5)
+    x = torch.rand(n, 3, hw, hw)
+    w = _bf(torch.randn(cout, 3, 7, 7) * 0.05)
+    b = torch.randn(cout) * 0.1
+    xs = co.stem_space_to_depth(x.to(DEV))
+    w2 = co.stem_weight(co.nhwc(w.to(DEV)))
+    oh, ow, _, _ = co.stem_geometry(hw, hw)
+    yp, idx = co.stem_fwd_pool(xs, w2, b.to(DEV), oh, ow)
+    gp = co.nhwc(torch.randn(n, cout, oh // 2, ow // 2).to(DEV), torch.bfloat16)
+    dz = ym._pool_bwd_idx(yp, idx, gp, fuse_leaky=leaky)
+    dw_ref, db_ref = co.stem_wgrad(xs, dz)
+    dw, db = co.stem_wgrad_pool(xs, gp, idx, yp if leaky else None)
+    assert float((dw - dw_ref).abs().max()) <= 1e-5 * float(dw_ref.abs().max()) + 1e-6
+    assert float((db - db_ref).abs().max()) <= 1e-5 * float(db_ref.abs().max()) + 1e-6

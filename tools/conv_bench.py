@@ -39,10 +39,13 @@ def main():
             dz = torch.randn(a.batch, cout, oh, ow, device=dev).to(torch.bfloat16).contiguous(memory_format=co.CL)
             xs = co.stem_space_to_depth(x)
             w2 = co.stem_weight(w)
+            gp = torch.randn(a.batch, cout, oh // 2, ow // 2, device=dev).to(torch.bfloat16).contiguous(memory_format=co.CL)
+            yp, pidx = co.stem_fwd_pool(xs, w2, b, oh, ow)
             flops = 2.0 * a.batch * oh * ow * cout * 147
             line = f"L0     3-> 192 k7 s2 448^2  GF={flops / 1e9:7.1f}"
             for op, fn in (("s2d", lambda: co.stem_space_to_depth(x)), ("fwd", lambda: co.stem_fwd(xs, w2, b, oh, ow)),
-                           ("fwdpool", lambda: co.stem_fwd_pool(xs, w2, b, oh, ow)), ("wgrad", lambda: co.stem_wgrad(xs, dz))):
+                           ("fwdpool", lambda: co.stem_fwd_pool(xs, w2, b, oh, ow)), ("wgrad", lambda: co.stem_wgrad(xs, dz)),
+                           ("wgradpool", lambda: co.stem_wgrad_pool(xs, gp, pidx, yp))):
                 if op != "s2d" and op not in tot:
                     continue
                 for _ in range(2):

@@ -289,3 +289,20 @@ def stem_wgrad(xs, dz):
                                                L.c_int(ws), L.c_int(oh), L.c_int(ow), L.c_int(cout), L.c_int(0),
                                                L.ptr(ws_buf), L.c_size(nbytes), L.stream()), "yfs_conv2d_stem_wgrad_bf16")
     return stem_weight_grad(dw2, cout), db
+
+
+def stem_wgrad_pool(xs, dy_pooled, idx, y_pooled, slope=0.1):
+    """stem_wgrad for a stem whose output went through LeakyReLU and the fused 2x2 pool, from the pooled side:
+    (pooled gradient, argmax record, pooled activation) instead of a full-resolution dz.  Same return."""
+    dy_pooled = nhwc(dy_pooled, torch.bfloat16)
+    n, _, hs, ws = xs.shape
+    cout, oh, ow = dy_pooled.shape[1], 2 * dy_pooled.shape[2], 2 * dy_pooled.shape[3]
+    dw2 = torch.empty(cout, 256, device=xs.device, dtype=torch.float32)
+    db = torch.empty(cout, device=xs.device, dtype=torch.float32)
+    nbytes = L.lib().yfs_conv2d_stem_wgrad_workspace_bytes(L.i64(n), L.c_int(oh), L.c_int(ow), L.c_int(cout))
+    ws_buf = workspace(nbytes, xs.device)
+    L.check(L.lib().yfs_conv2d_stem_wgrad_pool_bf16(L.ptr(xs), L.ptr(dy_pooled), L.ptr(idx), L.ptr(y_pooled), L.ptr(dw2),
+                                                    L.ptr(db), L.i64(n), L.c_int(hs), L.c_int(ws), L.c_int(oh), L.c_int(ow),
+                                                    L.c_int(cout), L.c_float(slope), L.c_int(0), L.ptr(ws_buf),
+                                                    L.c_size(nbytes), L.stream()), "yfs_conv2d_stem_wgrad_pool_bf16")
+    return stem_weight_grad(dw2, cout), db

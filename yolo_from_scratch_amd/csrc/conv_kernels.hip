@@ -407,7 +407,9 @@ int launch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
 // count quantises well on 256 CUs (196, 392, 3136 tiles), but loses when it does not (98, 784) or when K is short
 // (four-pass epilogue); it is chosen by the round-count model below.  Tried and rejected: 256x128 / 8 waves /
 // 3 stages (875-990), 32-deep rings at four workgroups per CU (790-880), 32-deep 4/5-stage rings (780-870),
-// 256x128 / 4 waves / 32-deep (810-980), issuing the loads between the MFMAs instead of in a burst (-6 %).
+// 256x128 / 4 waves / 32-deep (810-980), issuing the loads between the MFMAs instead of in a burst (-6 %),
+// 256x256 / 4 waves of 128x128 at one wave per SIMD with all 256 AGPRs as accumulators (the vendor GEMM's shape;
+// compiles without spills but the compiler's schedule leaves the single wave exposed: 730-890).
 // 128x192 serves the 192-channel outputs (pixel tile read once instead of three times with 128x64).  YFS_IGEMM_TILE=128|256|2562 forces a variant for benchmarking.
 template <int EPI, bool SUB>
 int dispatch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
@@ -518,8 +520,12 @@ FastDiv make_fastdiv(unsigned d) {
 __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) { return (__umulhi(n, f.mul) + n) >> f.shift; }
 
 struct WgradArgs {
-    const bf16_t* dz;   // [M][Cout]
+    const bf16_t* dz;   // [M][Cout]   (POOLZ: the POOLED gradient [M/4][Cout])
     const bf16_t* x;    // [N,H,W,Cin]
+    const unsigned short* zidx;   // POOLZ: [M/4][Cout/8] eight 2-bit window positions each (the pool's argmax record)
+    const bf16_t* zy;             // POOLZ: pooled activation [M/4][Cout] for the LeakyReLU derivative, or null
+    float slope;
+    unsigned zidx_bytes;
     float* partial;     // [splits][Cout][taps*Cin]
     float* dbpart;      // [splits][taps*citiles][2][Cout] partial column sums of dz (bias gradient), or null
     int H, W, Cin, OH, OW, Cout, KH, KW, PS, stride, pad, M;   // PS: elements between adjacent pixels of x
@@ -546,7 +552,11 @@ __device__ __forceinline__ unsigned wg_addr(int pixel, int ch /* channel inside 
 }
 
 // BX = ci tile (MFMA rows), BZ = co tile (MFMA cols).  4 waves as 2 (ci) x 2 (co).
-template <int BX, int BZ>
+// POOLZ: the block is followed by a 2x2 max pool and nothing else reads its dz (the stem): instead of reading a
+// dz tensor that pool backward would have to write first (3/4 zeros), the dz tile is built in LDS from the pooled
+// gradient, the pool's 2-bit argmax record and the pooled activation (LeakyReLU derivative).  The reduction then
+// enumerates output pixels window-major (m = 4 * window + position) so that one window is four consecutive rows.
+template <int BX, int BZ, bool POOLZ>
 __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
     constexpr int FX = BX / 32, FZ = BZ / 32;          // fragments per wave
     constexpr int CX = BX / 8, CZ = BZ / 8;            // 16-byte chunks per pixel row
@@ -607,10 +617,20 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
     unsigned pixcache = 0;
     auto pixel_offsets = [&](int ktg) -> unsigned {
         const int m = (ktg + (lane >> 4)) * 64 + wave * 16 + (lane & 15);
-        const unsigned n = fdiv((unsigned)m, g.div_ohw);
-        const unsigned rem = (unsigned)m - n * g.div_ohw.d;
-        const unsigned oh = fdiv(rem, g.div_ow);
-        const unsigned ow = rem - oh * g.div_ow.d;
+        unsigned n, oh, ow;
+        if (POOLZ) {   // div_ohw / div_ow divide by the POOLED grid here
+            const unsigned q = (unsigned)m >> 2, sub = (unsigned)m & 3u;
+            n = fdiv(q, g.div_ohw);
+            const unsigned rem = q - n * g.div_ohw.d;
+            const unsigned py = fdiv(rem, g.div_ow);
+            oh = 2 * py + (sub >> 1);
+            ow = 2 * (rem - py * g.div_ow.d) + (sub & 1);
+        } else {
+            n = fdiv((unsigned)m, g.div_ohw);
+            const unsigned rem = (unsigned)m - n * g.div_ohw.d;
+            oh = fdiv(rem, g.div_ow);
+            ow = rem - oh * g.div_ow.d;
+        }
         const int ih = (int)oh * g.stride, iw = (int)ow * g.stride;
         const bool ok = m < g.M && (unsigned)(ih - g.pad + kh) < (unsigned)g.H && (unsigned)(iw - g.pad + kw) < (unsigned)g.W;
         return ok ? (unsigned)((((int)n * g.H + ih) * g.W + iw) * g.PS) * 2u + tapoff : kPixOOB;
@@ -621,18 +641,92 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
         const int t = (kt - kt0) & 3;
         if (t == 0) pixcache = pixel_offsets(kt);
         const unsigned zk = (unsigned)kt * (unsigned)(64 * 2) * (unsigned)g.Cout;
+        if (!POOLZ) {
 #pragma unroll
-        for (int i = 0; i < LZ; ++i) {
-            // (a typed local: with a type-dependent offset expression the host pass re-checks the builtin at
-            //  instantiation, fails silently and drops the kernel's launch stub)
-            const unsigned off = zoff[i] + zk;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(srz, (lds_ptr)(base + XBYTES + (wave_u * LZ + i) * 1024), 16, off, 0, 0, 0);
+            for (int i = 0; i < LZ; ++i) {
+                // (a typed local: with a type-dependent offset expression the host pass re-checks the builtin at
+                //  instantiation, fails silently and drops the kernel's launch stub)
+                const unsigned off = zoff[i] + zk;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srz, (lds_ptr)(base + XBYTES + (wave_u * LZ + i) * 1024), 16, off, 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int i = 0; i < LX; ++i) {
             const int src = xsrc[i] + t * 64;
             const unsigned off = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)pixcache) + xchb[i];
             __builtin_amdgcn_raw_ptr_buffer_load_lds(srx, (lds_ptr)(base + (wave_u * LX + i) * 1024), 16, off, 0, 0, 0);
+        }
+    };
+
+    // POOLZ: a 64-row k-tile is 16 windows; one item = (window, 8-channel chunk): 16 B of pooled gradient and one
+    // 16-bit position record (+ 16 B of pooled activation when the LeakyReLU derivative is still to be applied),
+    // fetched into registers one tile ahead (descriptor loads: windows past the end read zeros) and expanded into
+    // four LDS rows after the current tile's MFMAs.  The expansion works on bf16 PAIRS: E holds the one-hot window
+    // position of both halves, (E >> k) & 0x00010001 is a {0,1} pair, and a packed 16-bit multiply keeps or clears
+    // each half (15 VALU per pair for all four rows; element-wise selects cost ~10x that and dominated the kernel).
+    constexpr int ZITEMS = 16 * CZ;
+    constexpr int NZI = (ZITEMS + kThreads - 1) / kThreads;
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    u32x4 zg[NZI], zyv[NZI];
+    unsigned zpk[NZI], zgoff[NZI], zioff[NZI], zlds[NZI][4];
+    const __amdgpu_buffer_rsrc_t sri = make_rsrc(POOLZ ? (const void*)g.zidx : (const void*)g.dz, POOLZ ? g.zidx_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t sry = make_rsrc((POOLZ && g.zy) ? g.zy : g.dz, g.zbytes);
+    const bool zleaky = POOLZ && g.zy != nullptr;
+    if (POOLZ) {
+#pragma unroll
+        for (int i = 0; i < NZI; ++i) {
+            const int item = tid + i * kThreads;
+            const int w = item / CZ, c = item % CZ;
+            zgoff[i] = ((unsigned)w * (unsigned)g.Cout + (unsigned)co0 + (unsigned)c * 8u) * 2u;
+            zioff[i] = ((unsigned)w * (unsigned)(g.Cout >> 3) + (unsigned)(co0 >> 3) + (unsigned)c) * 2u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int pixel = 4 * w + k;
+                zlds[i][k] = (unsigned)(XBYTES + pixel * (CZ * 16) + wg_swz<CZ>(pixel, c) * 16);
+            }
+        }
+    }
+    auto zload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < NZI; ++i) {
+            if (ZITEMS % kThreads != 0 && i == NZI - 1 && tid + i * kThreads >= ZITEMS) continue;
+            const unsigned off = zgoff[i] + (unsigned)kt * 32u * (unsigned)g.Cout;          // 16 windows x Cout x 2 B
+            const unsigned ioff = zioff[i] + (unsigned)kt * 32u * (unsigned)(g.Cout >> 3);
+            zg[i] = buf_load16(srz, off);
+            if (zleaky) zyv[i] = buf_load16(sry, off);
+            zpk[i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(sri, ioff, 0, 0);
+        }
+    };
+    auto zexpand = [&](int buf) {
+        unsigned char* tb = smem + buf * TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < NZI; ++i) {
+            if (ZITEMS % kThreads != 0 && i == NZI - 1 && tid + i * kThreads >= ZITEMS) continue;
+            u32x4 r[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                unsigned gw = zg[i][d];
+                if (zleaky) {   // same rounding as pool backward: bf16(float(g) * slope) where the activation is <= 0
+                    const unsigned yw = zyv[i][d];
+                    const float ylo = __uint_as_float(yw << 16), yhi = __uint_as_float(yw & 0xFFFF0000u);
+                    const bf16_t slo = (bf16_t)(__uint_as_float(gw << 16) * g.slope);
+                    const bf16_t shi = (bf16_t)(__uint_as_float(gw & 0xFFFF0000u) * g.slope);
+                    const unsigned lo16 = ylo > 0.0f ? (gw & 0xFFFFu) : (unsigned)__builtin_bit_cast(unsigned short, slo);
+                    const unsigned hi16 = yhi > 0.0f ? (gw >> 16) : (unsigned)__builtin_bit_cast(unsigned short, shi);
+                    gw = lo16 | (hi16 << 16);
+                }
+                const unsigned lo = (zpk[i] >> (4 * d)) & 3u, hi = (zpk[i] >> (4 * d + 2)) & 3u;
+                const unsigned E = (1u << lo) | (0x10000u << hi);
+                const u16x2 gv2 = __builtin_bit_cast(u16x2, gw);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned e = (E >> k) & 0x00010001u;
+                    const u16x2 prod = gv2 * __builtin_bit_cast(u16x2, e);
+                    r[k][d] = __builtin_bit_cast(unsigned, prod);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4*>(tb + zlds[i][k]) = r[k];
         }
     };
 
@@ -699,11 +793,18 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
         }
     };
 
-    if (kt0 < kt1) stage_tile(kt0, 0);
+    if (kt0 < kt1) {
+        stage_tile(kt0, 0);
+        if (POOLZ) zload(kt0);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (POOLZ && kt0 < kt1) zexpand(0);
     __syncthreads();
     for (int kt = kt0; kt < kt1; ++kt) {
-        if (kt + 1 < kt1) stage_tile(kt + 1, ((kt - kt0) + 1) & 1);
+        if (kt + 1 < kt1) {
+            stage_tile(kt + 1, ((kt - kt0) + 1) & 1);
+            if (POOLZ) zload(kt + 1);
+        }
         const int mode = (do_db && dbc == tci) ? 1 + wx : 0;   // 0: no column sum; 1 / 2: this wave sums k-half 0 / 1
         dbc = dbc + 1 == inner ? 0 : dbc + 1;
         const unsigned char* xb = smem + ((kt - kt0) & 1) * TILE_BYTES;
@@ -711,6 +812,8 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
         else if (mode == 1) tile_mfma(xb, std::integral_constant<int, 1>());
         else tile_mfma(xb, std::integral_constant<int, 2>());
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA of the next tile has landed (vmcnt tracks it)
+        // (the slot written here was last read two barriers ago)
+        if (POOLZ && kt + 1 < kt1) zexpand(((kt - kt0) + 1) & 1);
         __syncthreads();
     }
 
@@ -841,10 +944,10 @@ WgradPlan plan_wgrad(int64_t M, int Cin, int Cout, int taps) {
     return p;
 }
 
-template <int BX, int BZ>
+template <int BX, int BZ, bool POOLZ = false>
 int launch_wgrad(WgradArgs& g, const WgradPlan& p, hipStream_t s) {
     const size_t lds = 2 * (size_t)(BX + BZ) * 128;
-    auto kern = wgrad_kernel<BX, BZ>;
+    auto kern = wgrad_kernel<BX, BZ, POOLZ>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         YFS_REQUIRE(e == hipSuccess, YFS_ERR_LAUNCH, "yfs_conv2d_wgrad_bf16: cannot reserve %zu bytes of LDS", lds);
@@ -869,7 +972,8 @@ namespace {
 // shared by the regular and the stem entry points.  x: pixels PS elements apart, Cin reduced channels per tap.
 int wgrad_common(const char* fn, const void* x, const void* dz, float* dw, float* db, int64_t N, int H, int W, int PS, int Cin,
                  int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int accumulate, void* workspace,
-                 size_t workspace_bytes, hipStream_t s) {
+                 size_t workspace_bytes, hipStream_t s, const void* pool_idx = nullptr, const void* y_pooled = nullptr,
+                 float slope = 0.0f) {
     const int64_t M = N * OH * OW;
     const int taps = KH * KW;
     WgradPlan p = plan_wgrad(M, Cin, Cout, taps);
@@ -886,6 +990,16 @@ int wgrad_common(const char* fn, const void* x, const void* dz, float* dw, float
     g.ktiles_per_split = p.ktiles_per_split;
     g.div_ohw = make_fastdiv((unsigned)(OH * OW)); g.div_ow = make_fastdiv((unsigned)OW);
     int rc;
+    if (pool_idx) {   // dz given as (pooled gradient, argmax record, pooled activation): see wgrad_kernel POOLZ
+        YFS_REQUIRE(p.bx == 64 && OH % 2 == 0 && OW % 2 == 0, YFS_ERR_UNSUPPORTED,
+                    "%s: the pooled-gradient form needs a 64-wide reduction tile and an even %dx%d output", fn, OH, OW);
+        g.zidx = (const unsigned short*)pool_idx; g.zy = (const bf16_t*)y_pooled; g.slope = slope;
+        g.zbytes = (unsigned)(M / 4 * Cout * 2); g.zidx_bytes = (unsigned)(M / 4 * (Cout / 8) * 2);
+        g.div_ohw = make_fastdiv((unsigned)((OH / 2) * (OW / 2))); g.div_ow = make_fastdiv((unsigned)(OW / 2));
+        if (p.bz == 192) rc = launch_wgrad<64, 192, true>(g, p, s);
+        else if (p.bz == 128) rc = launch_wgrad<64, 128, true>(g, p, s);
+        else rc = launch_wgrad<64, 64, true>(g, p, s);
+    } else
     if (p.bx == 128 && p.bz == 128) rc = launch_wgrad<128, 128>(g, p, s);
     else if (p.bx == 128 && p.bz == 64) rc = launch_wgrad<128, 64>(g, p, s);
     else if (p.bx == 64 && p.bz == 128) rc = launch_wgrad<64, 128>(g, p, s);
@@ -1033,6 +1147,16 @@ YFS_API int yfs_conv2d_stem_wgrad_bf16(const void* xs, const void* dz, float* dw
     if (rc) return rc;
     return wgrad_common("yfs_conv2d_stem_wgrad_bf16", xs, dz, dw2, db, N, Hs, Ws, kStemC, 64, OH, OW, Cout, kStemKH, 1, 1, 0,
                         accumulate, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+YFS_API int yfs_conv2d_stem_wgrad_pool_bf16(const void* xs, const void* dy_pooled, const void* pool_idx, const void* y_pooled,
+                                            float* dw2, float* db, int64_t N, int Hs, int Ws, int OH, int OW, int Cout, float slope,
+                                            int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    YFS_REQUIRE(xs && dy_pooled && pool_idx && dw2, YFS_ERR_INVALID_ARG, "yfs_conv2d_stem_wgrad_pool_bf16: null pointer");
+    int rc = stem_check("yfs_conv2d_stem_wgrad_pool_bf16", N, Hs, Ws, OH, OW, Cout);
+    if (rc) return rc;
+    return wgrad_common("yfs_conv2d_stem_wgrad_pool_bf16", xs, dy_pooled, dw2, db, N, Hs, Ws, kStemC, 64, OH, OW, Cout, kStemKH, 1, 1,
+                        0, accumulate, workspace, workspace_bytes, (hipStream_t)stream, pool_idx, y_pooled, slope);
 }
 
 // =============================== helpers ========================================================

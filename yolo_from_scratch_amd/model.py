@@ -22,6 +22,7 @@ from . import conv_ops as co
 SLOPE = 0.1
 _TWO_STREAMS = os.environ.get("YFS_WGRAD_STREAM", "1") != "0"
 _FUSE_POOL = os.environ.get("YFS_FUSE_POOL", "1") != "0"
+_FUSE_STEM_POOL_BWD = os.environ.get("YFS_FUSE_STEM_POOL_BWD", "1") != "0"
 
 
 def _pool_fwd(x):
@@ -117,14 +118,18 @@ class _ConvPlan:
             return oh, ow
         return co.out_hw(h, w, self.k, self.stride)
 
-    def wgrad(self, gemm_in, dz, weight, bias):
+    def wgrad(self, gemm_in, dz, weight, bias, pooled=None):
         """Weight / bias gradients: written into the parameters' gradient sinks when they have one (returns
-        None then), else returned (dw in the weight's logical shape, channels_last fp32)."""
+        None then), else returned (dw in the weight's logical shape, channels_last fp32).
+        ``pooled`` = (idx, y_pooled): ``dz`` is then the gradient of the fused pool's OUTPUT (stem only)."""
         from .train import write_grad
         wsink = getattr(weight, "_yfs_grad_sink", None)
         bsink = getattr(bias, "_yfs_grad_sink", None)
         if self.stem:
-            dwv, db = co.stem_wgrad(gemm_in, dz)       # [Cout, 147] in (kh, kw, c) order
+            if pooled is not None:
+                dwv, db = co.stem_wgrad_pool(gemm_in, dz, pooled[0], pooled[1], SLOPE)
+            else:
+                dwv, db = co.stem_wgrad(gemm_in, dz)       # [Cout, 147] in (kh, kw, c) order
             cout, cin, k, _ = weight.shape
 
             def put_w(sink, acc):
@@ -304,12 +309,23 @@ class _BackboneFn(torch.autograd.Function):
         # the small split-K reductions) overlap the other instead of leaving CUs idle.
         main = torch.cuda.current_stream()
         side = _side_stream(dy.device) if _TWO_STREAMS else None
+        # LeakyReLU derivative: every block's input (i > 0) is a LeakyReLU output, pooled or not, and a pooled value
+        # has the sign of the element the pool routed to — so each dgrad applies the mask of ITS input in its
+        # epilogue (fp32, before the one rounding to bf16) and pool backward only routes.  A pool that ends the chain
+        # has no dgrad after it and applies the mask itself.
+        pooled = None
         for i in range(last, -1, -1):
             if stages[i] == "P":
-                g = _pool_bwd_idx(acts[i], gins[i], g, fuse_leaky=(i > 0 and stages[i - 1] != "P"))
+                if _FUSE_STEM_POOL_BWD and i == 1 and plans[0] is not None and plans[0].stem:
+                    # nothing but the stem's weight gradient reads this pool's input gradient: that kernel builds
+                    # its dz tiles from the pooled side itself, and the full-resolution tensor is never written
+                    pooled = (gins[i], acts[i] if i == last else None)
+                    continue
+                g = _pool_bwd_idx(acts[i], gins[i], g, fuse_leaky=(i == last))
                 continue
             plan = plans[i]
             pi -= 2
+            extra = {"pooled": pooled} if (i == 0 and pooled is not None) else {}
             if side is not None:
                 ev = torch.cuda.Event()
                 ev.record(main)
@@ -317,18 +333,19 @@ class _BackboneFn(torch.autograd.Function):
                     side.wait_event(ev)
                     g.record_stream(side)
                     gins[i].record_stream(side)
-                    dw, db = plan.wgrad(gins[i], g, ctx.params[pi], ctx.params[pi + 1])
+                    for t in (pooled or ()):
+                        if t is not None:
+                            t.record_stream(side)
+                    dw, db = plan.wgrad(gins[i], g, ctx.params[pi], ctx.params[pi + 1], **extra)
                     for t in (dw, db):
                         if t is not None:
                             t.record_stream(main)
             else:
-                dw, db = plan.wgrad(gins[i], g, ctx.params[pi], ctx.params[pi + 1])
+                dw, db = plan.wgrad(gins[i], g, ctx.params[pi], ctx.params[pi + 1], **extra)
             grads[pi], grads[pi + 1] = dw, db
             if i == 0:
                 break
-            prev_is_conv = stages[i - 1] != "P"
-            g = co.conv_dgrad(g, plan.wt16, acts[i - 1].shape[2:], plan.stride,
-                              x_act=acts[i - 1] if prev_is_conv else None, slope=SLOPE)
+            g = co.conv_dgrad(g, plan.wt16, acts[i - 1].shape[2:], plan.stride, x_act=acts[i - 1], slope=SLOPE)
         if side is not None:
             main.wait_stream(side)
         ctx.acts = ctx.gins = ctx.plans = ctx.params = None
