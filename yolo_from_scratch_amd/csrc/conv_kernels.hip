@@ -529,6 +529,11 @@ struct WgradArgs {
     float* partial;     // [splits][Cout][taps*Cin]
     float* dbpart;      // [splits][taps*citiles][2][Cout] partial column sums of dz (bias gradient), or null
     int H, W, Cin, OH, OW, Cout, KH, KW, PS, stride, pad, M;   // PS: elements between adjacent pixels of x
+    // A ci tile wider than 64 normally covers contiguous channels; for the stem's row-pair form (two kernel rows
+    // of 64 contiguous elements each per "tap") every group of 64 channels sits xgroup_bytes further on and one tap
+    // advances kh_mul input rows.
+    unsigned xgroup_bytes;   // 128 = contiguous
+    int kh_mul;              // 1 normally
     unsigned xbytes, zbytes;
     int cotiles, citiles, splits, ktiles, ktiles_per_split;
     FastDiv div_ohw, div_ow;
@@ -610,10 +615,11 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
     for (int i = 0; i < LX; ++i) {
         const int l = (wave * LX + i) * 64 + lane;
         const int pix = l / CX;
-        xchb[i] = (unsigned)(wg_swz<CX>(pix, l % CX) * 16);
+        const int cs = wg_swz<CX>(pix, l % CX);
+        xchb[i] = (unsigned)((cs & 7) * 16) + (unsigned)(cs >> 3) * g.xgroup_bytes;
         xsrc[i] = (pix - wave * 16) * 4;   // bpermute byte address of the lane holding that pixel (first k-tile of a group)
     }
-    const unsigned tapoff = (unsigned)(((kh - g.pad) * g.W + (kw - g.pad)) * g.PS + ci0) * 2u;   // wraps; added mod 2^32
+    const unsigned tapoff = (unsigned)(((kh * g.kh_mul - g.pad) * g.W + (kw - g.pad)) * g.PS + ci0) * 2u;   // wraps; added mod 2^32
     unsigned pixcache = 0;
     auto pixel_offsets = [&](int ktg) -> unsigned {
         const int m = (ktg + (lane >> 4)) * 64 + wave * 16 + (lane & 15);
@@ -632,10 +638,12 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
             ow = rem - oh * g.div_ow.d;
         }
         const int ih = (int)oh * g.stride, iw = (int)ow * g.stride;
-        const bool ok = m < g.M && (unsigned)(ih - g.pad + kh) < (unsigned)g.H && (unsigned)(iw - g.pad + kw) < (unsigned)g.W;
+        const bool ok = m < g.M && (unsigned)(ih - g.pad + kh * g.kh_mul) < (unsigned)g.H &&
+                        (unsigned)(iw - g.pad + kw) < (unsigned)g.W;
         return ok ? (unsigned)((((int)n * g.H + ih) * g.W + iw) * g.PS) * 2u + tapoff : kPixOOB;
     };
 
+    // LDS: [x tile | dz tile] x 2 ring slots
     auto stage_tile = [&](int kt, int buf) {
         unsigned char* base = smem + buf * TILE_BYTES;
         const int t = (kt - kt0) & 3;
@@ -658,64 +666,78 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
         }
     };
 
-    // POOLZ: a 64-row k-tile is 16 windows; one item = (window, 8-channel chunk): 16 B of pooled gradient and one
-    // 16-bit position record (+ 16 B of pooled activation when the LeakyReLU derivative is still to be applied),
-    // fetched into registers one tile ahead (descriptor loads: windows past the end read zeros) and expanded into
-    // four LDS rows after the current tile's MFMAs.  The expansion works on bf16 PAIRS: E holds the one-hot window
-    // position of both halves, (E >> k) & 0x00010001 is a {0,1} pair, and a packed 16-bit multiply keeps or clears
-    // each half (15 VALU per pair for all four rows; element-wise selects cost ~10x that and dominated the kernel).
-    constexpr int ZITEMS = 16 * CZ;
-    constexpr int NZI = (ZITEMS + kThreads - 1) / kThreads;
+    // POOLZ: a 64-row k-tile is 16 windows.  One item = (window, 4-channel half chunk): 8 B of pooled gradient and one
+    // byte of window positions (+ 8 B of pooled activation when the LeakyReLU derivative is still to be applied),
+    // exactly CZ/8 items per thread.  Items are fetched into registers TWO tiles ahead (descriptor loads: windows past
+    // the end read zeros) and expanded into the four LDS rows of the next tile's dz slot inside the current tile's
+    // MFMA block, so the VALU work runs under the matrix pipe instead of in a phase of its own.  The expansion works
+    // on bf16 PAIRS: E holds the one-hot window position of both halves, (E >> k) & 0x00010001 is a {0,1} pair, and a
+    // packed 16-bit multiply keeps or clears each half (16 VALU per pair for all four rows; element-wise selects cost
+    // ~10x that and dominated the kernel).
+    constexpr int NZH = CZ / 8;
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-    u32x4 zg[NZI], zyv[NZI];
-    unsigned zpk[NZI], zgoff[NZI], zioff[NZI], zlds[NZI][4];
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 zcur[NZH], znxt[NZH], zynxt[NZH];
+    unsigned zpcur[NZH], zpnxt[NZH], zgoff[NZH], zioff[NZH], zlds[NZH][4];
     const __amdgpu_buffer_rsrc_t sri = make_rsrc(POOLZ ? (const void*)g.zidx : (const void*)g.dz, POOLZ ? g.zidx_bytes : 0u);
     const __amdgpu_buffer_rsrc_t sry = make_rsrc((POOLZ && g.zy) ? g.zy : g.dz, g.zbytes);
     const bool zleaky = POOLZ && g.zy != nullptr;
     if (POOLZ) {
 #pragma unroll
-        for (int i = 0; i < NZI; ++i) {
-            const int item = tid + i * kThreads;
-            const int w = item / CZ, c = item % CZ;
-            zgoff[i] = ((unsigned)w * (unsigned)g.Cout + (unsigned)co0 + (unsigned)c * 8u) * 2u;
-            zioff[i] = ((unsigned)w * (unsigned)(g.Cout >> 3) + (unsigned)(co0 >> 3) + (unsigned)c) * 2u;
+        for (int i = 0; i < NZH; ++i) {
+            const int h = tid + i * kThreads;
+            const int w = h / (2 * CZ), rem = h % (2 * CZ), c = rem >> 1, half = rem & 1;
+            zgoff[i] = ((unsigned)w * (unsigned)g.Cout + (unsigned)co0 + (unsigned)(c * 8 + half * 4)) * 2u;
+            zioff[i] = ((unsigned)w * (unsigned)(g.Cout >> 3) + (unsigned)(co0 >> 3) + (unsigned)c) * 2u + (unsigned)half;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int pixel = 4 * w + k;
-                zlds[i][k] = (unsigned)(XBYTES + pixel * (CZ * 16) + wg_swz<CZ>(pixel, c) * 16);
+                zlds[i][k] = (unsigned)(XBYTES + pixel * (CZ * 16) + wg_swz<CZ>(pixel, c) * 16 + half * 8);
             }
         }
     }
-    auto zload = [&](int kt) {
+    auto zload_next = [&](int kt) {
 #pragma unroll
-        for (int i = 0; i < NZI; ++i) {
-            if (ZITEMS % kThreads != 0 && i == NZI - 1 && tid + i * kThreads >= ZITEMS) continue;
+        for (int i = 0; i < NZH; ++i) {
             const unsigned off = zgoff[i] + (unsigned)kt * 32u * (unsigned)g.Cout;          // 16 windows x Cout x 2 B
             const unsigned ioff = zioff[i] + (unsigned)kt * 32u * (unsigned)(g.Cout >> 3);
-            zg[i] = buf_load16(srz, off);
-            if (zleaky) zyv[i] = buf_load16(sry, off);
-            zpk[i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(sri, ioff, 0, 0);
+            znxt[i] = __builtin_amdgcn_raw_buffer_load_b64(srz, off, 0, 0);
+            if (zleaky) zynxt[i] = __builtin_amdgcn_raw_buffer_load_b64(sry, off, 0, 0);
+            zpnxt[i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(sri, ioff, 0, 0);
         }
     };
-    auto zexpand = [&](int buf) {
-        unsigned char* tb = smem + buf * TILE_BYTES;
+    // znxt -> zcur, with the LeakyReLU derivative applied when asked for (same rounding as pool backward:
+    // bf16(float(g) * slope) where the activation is <= 0)
+    auto zrotate = [&]() {
 #pragma unroll
-        for (int i = 0; i < NZI; ++i) {
-            if (ZITEMS % kThreads != 0 && i == NZI - 1 && tid + i * kThreads >= ZITEMS) continue;
-            u32x4 r[4];
+        for (int i = 0; i < NZH; ++i) {
+            zcur[i] = znxt[i];
+            zpcur[i] = zpnxt[i];
+        }
+        if (zleaky) {
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                unsigned gw = zg[i][d];
-                if (zleaky) {   // same rounding as pool backward: bf16(float(g) * slope) where the activation is <= 0
-                    const unsigned yw = zyv[i][d];
+            for (int i = 0; i < NZH; ++i)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const unsigned gw = zcur[i][d], yw = zynxt[i][d];
                     const float ylo = __uint_as_float(yw << 16), yhi = __uint_as_float(yw & 0xFFFF0000u);
                     const bf16_t slo = (bf16_t)(__uint_as_float(gw << 16) * g.slope);
                     const bf16_t shi = (bf16_t)(__uint_as_float(gw & 0xFFFF0000u) * g.slope);
                     const unsigned lo16 = ylo > 0.0f ? (gw & 0xFFFFu) : (unsigned)__builtin_bit_cast(unsigned short, slo);
                     const unsigned hi16 = yhi > 0.0f ? (gw >> 16) : (unsigned)__builtin_bit_cast(unsigned short, shi);
-                    gw = lo16 | (hi16 << 16);
+                    zcur[i][d] = lo16 | (hi16 << 16);
                 }
-                const unsigned lo = (zpk[i] >> (4 * d)) & 3u, hi = (zpk[i] >> (4 * d + 2)) & 3u;
+        }
+    };
+    auto zexpand = [&](int buf) {   // branch-free: meant to sit inside the MFMA basic block
+        unsigned char* tb = smem + buf * TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < NZH; ++i) {
+            u32x2 r[4];
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const unsigned gw = zcur[i][d];
+                const unsigned lo = (zpcur[i] >> (4 * d)) & 3u, hi = (zpcur[i] >> (4 * d + 2)) & 3u;
                 const unsigned E = (1u << lo) | (0x10000u << hi);
                 const u16x2 gv2 = __builtin_bit_cast(u16x2, gw);
 #pragma unroll
@@ -726,7 +748,7 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4*>(tb + zlds[i][k]) = r[k];
+            for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x2*>(tb + zlds[i][k]) = r[k];
         }
     };
 
@@ -757,9 +779,10 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
 
     // one 64-pixel k-tile; three straight-line copies (MODE is a compile-time tag) so that the column-sum MFMAs
     // do not put a branch inside the read/MFMA schedule
-    auto tile_mfma = [&](const unsigned char* xb, auto mode_tag) {
+    auto tile_mfma = [&](const unsigned char* xb, int nbuf, auto mode_tag) {
         constexpr int MODE = decltype(mode_tag)::value;
         const unsigned char* zb = xb + XBYTES;
+        if (POOLZ) zexpand(nbuf);   // next tile's dz rows; independent of everything below, scheduled among the MFMAs
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 xf[FX], zf[FZ];
@@ -795,25 +818,29 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
 
     if (kt0 < kt1) {
         stage_tile(kt0, 0);
-        if (POOLZ) zload(kt0);
+        if (POOLZ) zload_next(kt0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (POOLZ && kt0 < kt1) zexpand(0);
+    if (POOLZ) {
+        zrotate();
+        zexpand(0);
+        zload_next(kt0 + 1);
+    }
     __syncthreads();
     for (int kt = kt0; kt < kt1; ++kt) {
-        if (kt + 1 < kt1) {
-            stage_tile(kt + 1, ((kt - kt0) + 1) & 1);
-            if (POOLZ) zload(kt + 1);
+        const int nbuf = ((kt - kt0) + 1) & 1;
+        if (POOLZ) {   // registers: tile kt+1 becomes current, tile kt+2 starts loading (past the end: zeros / unused)
+            zrotate();
+            zload_next(kt + 2);
         }
+        if (kt + 1 < kt1) stage_tile(kt + 1, nbuf);
         const int mode = (do_db && dbc == tci) ? 1 + wx : 0;   // 0: no column sum; 1 / 2: this wave sums k-half 0 / 1
         dbc = dbc + 1 == inner ? 0 : dbc + 1;
         const unsigned char* xb = smem + ((kt - kt0) & 1) * TILE_BYTES;
-        if (mode == 0) tile_mfma(xb, std::integral_constant<int, 0>());
-        else if (mode == 1) tile_mfma(xb, std::integral_constant<int, 1>());
-        else tile_mfma(xb, std::integral_constant<int, 2>());
+        if (mode == 0) tile_mfma(xb, nbuf, std::integral_constant<int, 0>());
+        else if (mode == 1) tile_mfma(xb, nbuf, std::integral_constant<int, 1>());
+        else tile_mfma(xb, nbuf, std::integral_constant<int, 2>());
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA of the next tile has landed (vmcnt tracks it)
-        // (the slot written here was last read two barriers ago)
-        if (POOLZ && kt + 1 < kt1) zexpand(((kt - kt0) + 1) & 1);
         __syncthreads();
     }
 
@@ -912,10 +939,10 @@ struct WgradPlan {
 
 // taps = KH*KW.  Tile widths: 128 where the channel count allows, 192 for the two 192-channel tensors of the
 // backbone (feat.2's input, feat.0's output), else 64.  Only the instantiated (bx, bz) pairs are produced.
-WgradPlan plan_wgrad(int64_t M, int Cin, int Cout, int taps) {
+WgradPlan plan_wgrad(int64_t M, int Cin, int Cout, int taps, bool wide192 = false) {
     WgradPlan p;
     p.bx = (Cin % 128 == 0) ? 128 : ((Cin % 192 == 0 && Cout % 128 == 0) ? 192 : 64);
-    p.bz = (Cout % 128 == 0) ? 128 : ((Cout % 192 == 0 && p.bx == 64) ? 192 : 64);
+    p.bz = (Cout % 128 == 0) ? 128 : ((Cout % 192 == 0 && (p.bx == 64 || wide192)) ? 192 : 64);
     p.citiles = Cin / p.bx;
     p.cotiles = Cout / p.bz;
     p.ktiles = (int)yfs_cdiv(M, 64);
@@ -973,10 +1000,10 @@ namespace {
 int wgrad_common(const char* fn, const void* x, const void* dz, float* dw, float* db, int64_t N, int H, int W, int PS, int Cin,
                  int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int accumulate, void* workspace,
                  size_t workspace_bytes, hipStream_t s, const void* pool_idx = nullptr, const void* y_pooled = nullptr,
-                 float slope = 0.0f) {
+                 float slope = 0.0f, unsigned xgroup_bytes = 128, int kh_mul = 1) {
     const int64_t M = N * OH * OW;
     const int taps = KH * KW;
-    WgradPlan p = plan_wgrad(M, Cin, Cout, taps);
+    WgradPlan p = plan_wgrad(M, Cin, Cout, taps, pool_idx != nullptr);
     YFS_REQUIRE(workspace && workspace_bytes >= p.partial_bytes + p.db_bytes, YFS_ERR_WORKSPACE,
                 "%s: workspace needs %zu bytes, got %zu", fn, p.partial_bytes + p.db_bytes, workspace_bytes);
     YFS_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, YFS_ERR_WORKSPACE, "%s: workspace must be 16-byte aligned", fn);
@@ -985,20 +1012,21 @@ int wgrad_common(const char* fn, const void* x, const void* dz, float* dw, float
     g.dbpart = db ? (float*)((unsigned char*)workspace + p.partial_bytes) : nullptr;
     g.H = H; g.W = W; g.Cin = Cin; g.OH = OH; g.OW = OW; g.Cout = Cout; g.KH = KH; g.KW = KW; g.PS = PS; g.stride = stride; g.pad = pad;
     g.M = (int)M;
+    g.xgroup_bytes = xgroup_bytes; g.kh_mul = kh_mul;
     g.xbytes = (unsigned)(N * H * W * PS * 2); g.zbytes = (unsigned)(M * Cout * 2);
     g.cotiles = p.cotiles; g.citiles = p.citiles; g.splits = p.splits; g.ktiles = p.ktiles;
     g.ktiles_per_split = p.ktiles_per_split;
     g.div_ohw = make_fastdiv((unsigned)(OH * OW)); g.div_ow = make_fastdiv((unsigned)OW);
     int rc;
     if (pool_idx) {   // dz given as (pooled gradient, argmax record, pooled activation): see wgrad_kernel POOLZ
-        YFS_REQUIRE(p.bx == 64 && OH % 2 == 0 && OW % 2 == 0, YFS_ERR_UNSUPPORTED,
-                    "%s: the pooled-gradient form needs a 64-wide reduction tile and an even %dx%d output", fn, OH, OW);
+        YFS_REQUIRE(p.bx == 128 && OH % 2 == 0 && OW % 2 == 0, YFS_ERR_UNSUPPORTED,
+                    "%s: the pooled-gradient form needs a 128-wide reduction tile and an even %dx%d output", fn, OH, OW);
         g.zidx = (const unsigned short*)pool_idx; g.zy = (const bf16_t*)y_pooled; g.slope = slope;
         g.zbytes = (unsigned)(M / 4 * Cout * 2); g.zidx_bytes = (unsigned)(M / 4 * (Cout / 8) * 2);
         g.div_ohw = make_fastdiv((unsigned)((OH / 2) * (OW / 2))); g.div_ow = make_fastdiv((unsigned)(OW / 2));
-        if (p.bz == 192) rc = launch_wgrad<64, 192, true>(g, p, s);
-        else if (p.bz == 128) rc = launch_wgrad<64, 128, true>(g, p, s);
-        else rc = launch_wgrad<64, 64, true>(g, p, s);
+        if (p.bz == 192) rc = launch_wgrad<128, 192, true>(g, p, s);
+        else if (p.bz == 128) rc = launch_wgrad<128, 128, true>(g, p, s);
+        else rc = launch_wgrad<128, 64, true>(g, p, s);
     } else
     if (p.bx == 128 && p.bz == 128) rc = launch_wgrad<128, 128>(g, p, s);
     else if (p.bx == 128 && p.bz == 64) rc = launch_wgrad<128, 64>(g, p, s);
@@ -1045,6 +1073,7 @@ YFS_API int yfs_conv2d_wgrad_bf16(const void* x, const void* dz, float* dw, floa
 // implicit GEMM runs with KH=4, KW=1, C=64, pixel stride 16 and never materialises an im2col matrix.
 namespace {
 constexpr int kStemC = 16, kStemKH = 4;
+static int stem_ps() { static const int v = [] { const char* e = getenv("YFS_STEM_PS_EXPERIMENT"); return e ? atoi(e) : kStemC; }(); return v; }
 int stem_check(const char* fn, int64_t N, int Hs, int Ws, int OH, int OW, int Cout) {
     YFS_REQUIRE(N > 0 && Hs > 0 && Ws > 0 && OH > 0 && OW > 0 && Cout > 0, YFS_ERR_INVALID_ARG, "%s: non-positive dimension", fn);
     YFS_REQUIRE(OH + 3 <= Hs && OW + 4 <= Ws, YFS_ERR_INVALID_ARG,
@@ -1127,17 +1156,19 @@ YFS_API int yfs_conv2d_stem_fwd_pool_bf16(const void* xs, const void* w2, const 
                 "yfs_conv2d_stem_fwd_pool_bf16: conv output %dx%d must be even for the fused 2x2 pool", OH, OW);
     IgemmArgs g = {};
     g.x = (const bf16_t*)xs; g.w = (const bf16_t*)w2; g.bias = bias; g.out = (bf16_t*)y_pooled; g.pool_idx = (unsigned short*)pool_idx;
-    g.N = (int)N; g.H = Hs; g.W = Ws; g.C = 64; g.PS = kStemC; g.OH = OH; g.OW = OW; g.NOUT = Cout;
+    g.N = (int)N; g.H = Hs; g.W = Ws; g.C = 64; g.PS = stem_ps(); g.OH = OH; g.OW = OW; g.NOUT = Cout;
     g.KH = kStemKH; g.KW = 1; g.s_mul = 1; g.pad = 0; g.slope = slope;
     g.M = (int)(N * OH * OW);
-    g.xbytes = (unsigned)(N * Hs * Ws * kStemC * 2); g.wbytes = (unsigned)((int64_t)Cout * kStemKH * 64 * 2);
+    g.xbytes = (unsigned)(N * Hs * Ws * stem_ps() * 2); g.wbytes = (unsigned)((int64_t)Cout * kStemKH * 64 * 2);
     return dispatch_igemm<EPI_POOL, false>(g, (hipStream_t)stream, "yfs_conv2d_stem_fwd_pool_bf16");
 }
 
 YFS_API size_t yfs_conv2d_stem_wgrad_workspace_bytes(int64_t N, int OH, int OW, int Cout) {
     if (N <= 0 || OH <= 0 || OW <= 0 || Cout <= 0) return 0;
-    WgradPlan p = plan_wgrad(N * OH * OW, 64, Cout, kStemKH);
-    return p.partial_bytes + p.db_bytes;
+    const WgradPlan p = plan_wgrad(N * OH * OW, 64, Cout, kStemKH);
+    const WgradPlan q = plan_wgrad(N * OH * OW, 128, Cout, kStemKH / 2, true);   // the pooled (row-pair) form
+    const size_t a = p.partial_bytes + p.db_bytes, b = q.partial_bytes + q.db_bytes;
+    return a > b ? a : b;
 }
 
 YFS_API int yfs_conv2d_stem_wgrad_bf16(const void* xs, const void* dz, float* dw2, float* db, int64_t N, int Hs, int Ws, int OH,
@@ -1155,8 +1186,11 @@ YFS_API int yfs_conv2d_stem_wgrad_pool_bf16(const void* xs, const void* dy_poole
     YFS_REQUIRE(xs && dy_pooled && pool_idx && dw2, YFS_ERR_INVALID_ARG, "yfs_conv2d_stem_wgrad_pool_bf16: null pointer");
     int rc = stem_check("yfs_conv2d_stem_wgrad_pool_bf16", N, Hs, Ws, OH, OW, Cout);
     if (rc) return rc;
-    return wgrad_common("yfs_conv2d_stem_wgrad_pool_bf16", xs, dy_pooled, dw2, db, N, Hs, Ws, kStemC, 64, OH, OW, Cout, kStemKH, 1, 1,
-                        0, accumulate, workspace, workspace_bytes, (hipStream_t)stream, pool_idx, y_pooled, slope);
+    // two kernel rows per "tap": the 128-wide reduction tile is rows (2t, 2t+1) x 64 contiguous elements, so the dz
+    // tile built in LDS feeds twice the MFMA work of the one-row form (dw2 [Cout][4][64] == [Cout][2][128])
+    return wgrad_common("yfs_conv2d_stem_wgrad_pool_bf16", xs, dy_pooled, dw2, db, N, Hs, Ws, stem_ps(), 128, OH, OW, Cout,
+                        kStemKH / 2, 1, 1, 0, accumulate, workspace, workspace_bytes, (hipStream_t)stream, pool_idx, y_pooled,
+                        slope, (unsigned)(Ws * stem_ps() * 2), 2);
 }
 
 // =============================== helpers ========================================================
