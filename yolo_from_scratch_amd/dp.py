@@ -10,8 +10,12 @@ Design for the MI355X node:
     gradient (``notify``), ordered after the producing kernels by an event; ``finish`` makes the compute
     stream wait for all of them before clip_grad_norm_/SGD read the arena (the reference clips AFTER
     backward, :331-333, so the reduced gradient is what must be clipped);
-  * xGMI is point-to-point (7 links per GPU): a few large messages, not many small ones — the bucket
-    size is 256 MB by default, so the 1.06 GB payload travels as ~5 collectives.
+  * xGMI is point-to-point (7 links per GPU): large messages, but the LAST bucket (the first layers' gradients,
+    produced at the very end of backward) has nothing left to hide under, so it must be small.  fc.1 (820 MB) is
+    one message and goes first; the 242 MB of conv gradients travel as ~32 MB buckets while the remaining
+    dgrad/wgrad kernels run; the gradients of the first ``tail_bytes`` of the arena (feat.0-6, a few MB) are cut
+    at ``tail_bucket_bytes`` so the exposed tail is a latency-sized message (a single 256 MB conv bucket would
+    leave ~1.4 ms of a ~14.5 ms step exposed on 8 GPUs).
 Averaging: SUM all-reduce, then the 1/world factor is folded into the bf16->fp32 copy-back (compressed
 mode) or applied as one in-place scale on the side stream (fp32 mode).
 """
@@ -30,10 +34,12 @@ def register_producer_stream(stream):
 
 
 class GradComm:
-    def __init__(self, world_size=None, bucket_bytes=256 << 20, compress_bf16=False, group=None):
+    def __init__(self, world_size=None, bucket_bytes=32 << 20, compress_bf16=False, group=None,
+                 tail_bytes=16 << 20, tail_bucket_bytes=4 << 20):
         self.group = group
         self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.bucket_bytes = bucket_bytes
+        self.tail_bytes, self.tail_bucket_bytes = tail_bytes, min(tail_bucket_bytes, bucket_bytes)
         self.compress = compress_bf16
         self.buckets = []          # (start, end) element ranges of the flat arena, in issue order
         self.param_bucket = {}     # id(param) -> bucket index
@@ -47,7 +53,7 @@ class GradComm:
     def attach(self, params, offsets, flat_g):
         """params / offsets as laid out by FlatSGD (registration order); buckets are cut from the END."""
         self.flat = flat_g
-        per = max(1, self.bucket_bytes // 4)
+        per, per_tail, tail = max(1, self.bucket_bytes // 4), max(1, self.tail_bucket_bytes // 4), self.tail_bytes // 4
         self.buckets, self.param_bucket = [], {}
         cur_hi, cur_lo, members = None, None, []
         for p, (off, n) in zip(reversed(params), reversed(offsets)):
@@ -55,7 +61,7 @@ class GradComm:
                 cur_hi = off + n
             cur_lo = off
             members.append(p)
-            if cur_hi - cur_lo >= per:
+            if cur_hi - cur_lo >= (per_tail if cur_hi <= tail else per):
                 self._close(cur_lo, cur_hi, members)
                 cur_hi, members = None, []
         if members:
