@@ -190,6 +190,20 @@ int yfs_conv2d_fwd_pool_bf16(const void *x, const void *w, const float *bias, vo
 int yfs_conv2d_stem_fwd_pool_bf16(const void *xs, const void *w2, const float *bias, void *y_pooled, void *pool_idx,
                                   int64_t N, int Hs, int Ws, int OH, int OW, int Cout, float slope, void *stream);
 
+/* Epilogue of fc.1  yolo_toy_regressor_torch.py:258-263  Linear(50176, 4096) -> LeakyReLU(0.1) -> Dropout(0.2),
+ * fused around a library GEMM.
+ * fwd: y[m][n] = drop(leaky(bias[n] + sum_{s<splits} partial[s][m][n])) as bf16; partial fp32 [splits][M][N] (the
+ *   split-K slabs of the GEMM, summed in slab order), bias may be NULL; drop keeps an element when its Philox4x32-10
+ *   uniform (key = seed, counter = element / 4) is >= p_drop and scales it by 1/(1-p_drop) (nn.Dropout training
+ *   semantics; p_drop = 0 = eval mode); keep [M][N] uint8 receives the mask (required when p_drop > 0).
+ * bwd: dz = dy * keep/(1-p_drop) * (y > 0 ? 1 : slope) as bf16 (y = the forward's output: a dropped or non-positive
+ *   element takes the slope branch, and a dropped one is zero anyway); db[n] = (accumulate ? db[n] : 0) + sum_m dz
+ *   (may be NULL). */
+int yfs_fc_epilogue_fwd_bf16(const float *partial, int splits, const float *bias, void *y, void *keep, int64_t M, int N,
+                             float slope, float p_drop, uint64_t seed, void *stream);
+int yfs_fc_epilogue_bwd_bf16(const void *dy, const void *y, const void *keep, void *dz, float *db, int64_t M, int N,
+                             float slope, float p_drop, int accumulate, void *stream);
+
 /* clip_grad_norm_ + SGD(momentum, weight_decay)  yolo_toy_regressor_torch.py:331-335, :378-381 on flat
  * fp32 arenas (all parameters / gradients / momentum buffers live in one allocation each).
  * yfs_sumsq_f32: sumsq_out[0] = sum g^2 (deterministic two-stage reduction).

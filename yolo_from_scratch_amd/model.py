@@ -18,11 +18,13 @@ import torch.nn.functional as F
 
 from . import _lib as L
 from . import conv_ops as co
+from . import fc_ops as fo
 
 SLOPE = 0.1
 _TWO_STREAMS = os.environ.get("YFS_WGRAD_STREAM", "1") != "0"
 _FUSE_POOL = os.environ.get("YFS_FUSE_POOL", "1") != "0"
 _FUSE_STEM_POOL_BWD = os.environ.get("YFS_FUSE_STEM_POOL_BWD", "1") != "0"
+_FUSE_FC = os.environ.get("YFS_FUSE_FC", "1") != "0"
 
 
 def _pool_fwd(x):
@@ -382,7 +384,9 @@ class _LinearFn(torch.autograd.Function):
     hand-written kernel sets), fp32 master weight, gradients written into the optimiser's arena."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, slope=None, p_drop=0.0, seed=0):
+        """``slope`` not None: the layer's LeakyReLU(slope) and Dropout(p_drop) run fused behind the GEMM
+        (fc_kernels.hip); the GEMM then leaves fp32 (split-K slabs for fc.1) and is rounded to bf16 once."""
         from .train import bf16_shadow
         x16 = x.to(torch.bfloat16)
         w16 = bf16_shadow(weight)
@@ -396,7 +400,19 @@ class _LinearFn(torch.autograd.Function):
         ctx.wb, ctx.in_dtype = (weight, bias), x.dtype
         m, k = x16.shape
         n = w16.shape[0]
-        if k >= 8192 and m * n <= (1 << 20) and k % 64 == 0:
+        ctx.fused = slope is not None
+        split = k >= 8192 and m * n <= (1 << 20) and k % 64 == 0
+        if ctx.fused:
+            if split:
+                S = 8
+                part = torch.bmm(x16.view(m, S, k // S).transpose(0, 1), w16.view(n, S, k // S).permute(1, 2, 0),
+                                 out_dtype=torch.float32)
+            else:
+                part = torch.mm(x16, w16.t(), out_dtype=torch.float32)
+            y, keep = fo.fc_epilogue_fwd(part, bias, slope, p_drop, seed)
+            ctx.epi = (y, keep, slope, p_drop)
+            return y
+        if split:
             # fc.1 (64 x 4096 x 50176): a plain GEMM has 16 output tiles for 256 CUs and runs at a third of the
             # rate the 411 MB weight stream allows; 8-way split-K as a batched GEMM with fp32 partials fills the
             # chip (0.25 -> 0.09 ms) and is more accurate than bf16 accumulation across the whole K.
@@ -413,7 +429,22 @@ class _LinearFn(torch.autograd.Function):
         (x16,) = ctx.saved_tensors
         w16 = ctx.w16
         weight, bias = ctx.wb
-        dy16 = dy.to(torch.bfloat16).contiguous()
+        db_fused = None
+        if ctx.fused:      # dropout mask x LeakyReLU derivative and the bias gradient in one pass over dy
+            y, keep, slope, p_drop = ctx.epi
+            got = {}
+
+            def put_b_fused(sink, acc):
+                if sink is None:
+                    db = torch.empty(y.shape[1], device=y.device, dtype=torch.float32)
+                    got["dz"] = fo.fc_epilogue_bwd(dy, y, keep, slope, p_drop, db=db)
+                    return db
+                got["dz"] = fo.fc_epilogue_bwd(dy, y, keep, slope, p_drop, db=sink, accumulate=acc)
+            db_fused = (write_grad(bias, put_b_fused),)
+            dy16 = got["dz"]
+            ctx.epi = None
+        else:
+            dy16 = dy.to(torch.bfloat16).contiguous()
         dx = torch.mm(dy16, w16).to(ctx.in_dtype) if ctx.needs_input_grad[0] else None
 
         def put_w(sink, acc):     # bf16 operands, fp32 result straight into the gradient arena (no bf16 round trip)
@@ -430,22 +461,44 @@ class _LinearFn(torch.autograd.Function):
             if sink is None:
                 return db
             sink.add_(db) if acc else sink.copy_(db)
-        dw, db = write_grad(weight, put_w), write_grad(bias, put_b)
+        dw = write_grad(weight, put_w)
+        db = db_fused[0] if db_fused is not None else write_grad(bias, put_b)
         ctx.wb = ctx.w16 = None
-        return dx, dw, db
+        return dx, dw, db, None, None, None
 
 
 class HipLinear(nn.Linear):
-    """nn.Linear with the same parameter names/init; bf16 compute, fp32 master weights."""
+    """nn.Linear with the same parameter names/init; bf16 compute, fp32 master weights.
+    ``fused_act`` = slope: the LeakyReLU(slope) that follows the layer (and the Dropout module handed to
+    ``fuse_dropout``) run in the layer's own epilogue; the modules themselves stay in the Sequential as identity
+    placeholders so the reference's indices and state-dict keys (fc.1, fc.4) are unchanged."""
 
-    def __init__(self, in_features, out_features):
+    def __init__(self, in_features, out_features, fused_act=None):
         super().__init__(in_features, out_features)
         self.weight._yfs_sink_capable = self.bias._yfs_sink_capable = True
+        self.fused_act = fused_act
+        self.__dict__["_drop_ref"] = None       # not a submodule: keeps the key names of the reference
+
+    def fuse_dropout(self, drop):
+        self.__dict__["_drop_ref"] = drop
 
     def forward(self, x):
         if not x.is_cuda:
             raise L.YfsError("HipLinear runs on the MI355X only")
-        return _LinearFn.apply(x, self.weight, self.bias)
+        if self.fused_act is None:
+            return _LinearFn.apply(x, self.weight, self.bias)
+        drop = self.__dict__.get("_drop_ref")
+        p = float(drop.p) if (drop is not None and drop.training) else 0.0
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0   # CPU generator: follows torch.manual_seed
+        return _LinearFn.apply(x, self.weight, self.bias, float(self.fused_act), p, seed)
+
+
+class FusedDropout(nn.Dropout):
+    """Placeholder at the reference's fc.3: the dropout already ran in fc.1's epilogue (p and train/eval mode are
+    read from this module at every call)."""
+
+    def forward(self, x):
+        return x
 
 
 class YoloRegressorModel(nn.Module):
@@ -477,11 +530,13 @@ class YoloRegressorModel(nn.Module):
         flat = 1024 * hw * hw
         self.fc = nn.Sequential(
             nn.Flatten(),
-            HipLinear(flat, 4096),
-            nn.LeakyReLU(0.1, inplace=True),
-            nn.Dropout(p_drop),
+            HipLinear(flat, 4096, fused_act=SLOPE if _FUSE_FC else None),
+            FusedLeakyReLU(0.1) if _FUSE_FC else nn.LeakyReLU(0.1, inplace=True),
+            FusedDropout(p_drop) if _FUSE_FC else nn.Dropout(p_drop),
             HipLinear(4096, head_out),
         )
+        if _FUSE_FC:
+            self.fc[1].fuse_dropout(self.fc[3])
 
     def forward(self, x):
         x = self.feat(x)
