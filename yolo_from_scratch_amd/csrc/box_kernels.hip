@@ -415,11 +415,14 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
     __syncthreads();
     const int nseg = ctl[2];
 
-    // ---- C: greedy suppression, one wave per class segment ----
-    for (int sg = wave; sg < nseg; sg += kThreads / 64) {
-        const int p0 = segs[sg];
+    // ---- C: greedy suppression per class segment ----
+    // The loop over kept boxes is serial per segment and every iteration costs the same ~45 VALU whether 5 or 64 lanes
+    // hold a member; config 4 has ~23 members per class.  A wave therefore takes TWO segments at a time, one per
+    // 32-lane half (each half reads "its" kept box out of lane i / lane 32 + i of the same registers); a pair in which
+    // either segment is longer than 32 falls back to one segment per wave.
+    auto seg_len = [&](int p0) {
         const unsigned long long c = key[p0] >> kClsShift;
-        int len = 0;   // segment length: leading run of class c from p0
+        int len = 0;   // leading run of class c from p0
         for (int base = p0; base < K; base += 64) {
             const int p = base + lane;
             const bool same = p < K && (key[p] >> kClsShift) == c;
@@ -428,6 +431,9 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
             len += __builtin_ctzll(~bal);
             break;
         }
+        return len;
+    };
+    auto one_segment = [&](int p0, int len) {
         if (len <= 64) {
             // member `lane` lives in this lane's registers; `removed` is wave-uniform
             const bool mine = lane < len;
@@ -469,6 +475,47 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
                 }
             }
         }
+    };
+    for (int sg = 2 * wave; sg < nseg; sg += 2 * (kThreads / 64)) {
+        const int pA = segs[sg];
+        const int lenA = seg_len(pA);
+        if (sg + 1 >= nseg) { one_segment(pA, lenA); break; }
+        const int pB = segs[sg + 1];
+        const int lenB = seg_len(pB);
+        if (lenA > 32 || lenB > 32) {
+            one_segment(pA, lenA);
+            one_segment(pB, lenB);
+            continue;
+        }
+        const int hl = lane & 31;
+        const bool upper = lane >= 32;
+        const int mylen = upper ? lenB : lenA;
+        const bool mine = hl < mylen;
+        const int sj = mine ? (int)(key[(upper ? pB : pA) + hl] & kSlotMask) : 0;
+        const float4 q = cbox[sj];
+        unsigned remA = 0, remB = 0;            // wave-uniform
+        const int lmax = lenA > lenB ? lenA : lenB;
+        for (int i = 0; i < lmax; ++i) {
+            const bool actA = i < lenA && !((remA >> i) & 1u), actB = i < lenB && !((remB >> i) & 1u);
+            if (!actA && !actB) continue;
+            float4 pa, pb;
+            pa.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.x), i));
+            pa.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.y), i));
+            pa.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.z), i));
+            pa.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.w), i));
+            pb.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.x), 32 + i));
+            pb.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.y), 32 + i));
+            pb.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.z), 32 + i));
+            pb.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.w), 32 + i));
+            const float4 p = upper ? pb : pa;
+            const float v = yfs_iou_corners(p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w);
+            const bool act = upper ? actB : actA;
+            const unsigned long long bal = __ballot(act && mine && hl > i && v > g.iou_thr);
+            remA |= (unsigned)bal;
+            remB |= (unsigned)(bal >> 32);
+        }
+        const unsigned myrem = upper ? remB : remA;
+        if (mine && !((myrem >> hl) & 1u)) kflag[sj] = 1;
     }
     if (tid == 0) ctl[1] = 0;
     __syncthreads();
@@ -634,6 +681,17 @@ YFS_API int yfs_decode_nms_f32(const float* raw, int64_t N, int S, int A, int C,
     const int64_t per = (int64_t)S * S * A;
     YFS_REQUIRE(per <= YFS_NMS_MAX_BOXES, YFS_ERR_UNSUPPORTED, "yfs_decode_nms_f32: %lld boxes per image exceeds %d",
                 (long long)per, YFS_NMS_MAX_BOXES);
+    // Default: two launches.  The decode is VALU-bound (25 expf per box) and perfectly parallel over boxes, while inside
+    // the per-image NMS workgroup it could only proceed in LDS-sized chunks of 128 boxes, each paying the staging latency
+    // on the image's critical path (7 chunks = 36 % of the kernel).  Decoded boxes / scores / classes are outputs of this
+    // entry point anyway, so the only extra traffic is the NMS kernel reading the 3.4 KB of scores per image back
+    // (+ the boxes that pass).  Measured on config 4: 0.102 -> two launches; YFS_NMS_FUSED=1 keeps the one-launch kernel.
+    static const bool fused = [] { const char* e = getenv("YFS_NMS_FUSED"); return e && atoi(e) != 0; }();
+    if (!fused) {
+        int rc = yfs_decode_grid_f32(raw, N, S, A, C, anchors, boxes, score, cls, nullptr, stream);
+        if (rc) return rc;
+        return yfs_nms_classwise_f32(boxes, score, cls, N, (int)per, score_thr, iou_thr, keep, count, stream);
+    }
     NmsArgs g = {};
     g.raw = raw; g.anchors = anchors; g.S = S; g.A_anch = A; g.C = C;
     g.boxes_out = (float4*)boxes; g.score_out = score; g.cls_out = cls;
