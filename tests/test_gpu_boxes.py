@@ -164,3 +164,30 @@ def test_config4_full_size_properties():
     assert (ks[valid] >= 0.05).all()
     d = np.diff(np.where(valid, ks, -np.inf), axis=1)
     assert (d[valid[:, 1:]] <= 0).all()
+
+
+def test_one_launch_fused_kernel_still_matches():
+    """YFS_NMS_FUSED=1 selects the one-launch decode+NMS kernel (the default is two launches); the switch is read once
+    per process, so the fused kernel is exercised in a child process and compared with the default path here."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    N, S, A, C = 6, 13, 5, 20
+    raw = synth.raw_head_v2(N, S, A, C, seed=77)
+    ref = [t.cpu().numpy() for t in y.decode_nms(_t(raw), _t(synth.VOC_ANCHORS[:A]), 0.05, 0.5)]
+    code = (
+        "import sys, numpy as np, torch\n"
+        "import yolo_from_scratch_amd as y\n"
+        "from yolo_from_scratch_amd import synth\n"
+        f"raw = synth.raw_head_v2({N}, {S}, {A}, {C}, seed=77)\n"
+        f"out = y.decode_nms(torch.from_numpy(raw).cuda(), torch.from_numpy(synth.VOC_ANCHORS[:{A}]).cuda(), 0.05, 0.5)\n"
+        "np.savez(sys.argv[1], *[t.cpu().numpy() for t in out])\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "fused.npz")
+        env = dict(os.environ, YFS_NMS_FUSED="1", PYTHONPATH=root)
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=env, cwd=root, timeout=110)
+        got = np.load(path)
+        for i, r in enumerate(ref):
+            np.testing.assert_array_equal(got[f"arr_{i}"], r)
