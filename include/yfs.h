@@ -217,6 +217,13 @@ int yfs_sumsq_f32(const float *g, int64_t n, float *sumsq_out, void *workspace, 
 int yfs_sgd_step_f32(float *p, const float *g, float *buf, int64_t n, const float *sumsq, float max_norm,
                      float lr, float momentum, float weight_decay, int first_step, void *p_bf16, void *stream);
 
+/* YOLOv1 grid targets from ground-truth boxes: the step between the reference's data path (largest mask box ->
+ * box_to_xywh_norm, yolo_toy_regressor_torch.py:98-119, :184-203) and the composite loss (SPEC.md 1; the grid
+ * encoding itself has no reference code, README.md:90-93 gives the convention).  gt [N,G,5] = (xc, yc, w, h, class)
+ * image-normalised, w <= 0 = padding.  target [N,S,S,5B+C] is written completely: zeros, and for every cell the
+ * LOWEST-index gt whose centre falls into it: box slot 0 = (xc*S - col, yc*S - row, w, h, 1), one-hot class. */
+int yfs_encode_targets_v1_f32(const float *gt, int64_t N, int G, int S, int B, int C, float *target, void *stream);
+
 /* k-means anchor clustering, assignment step (reference: README.md:56 names the feature; nearest code is the k=1
  * median prior estimate_size_priors, practice/yolo_toy_regressor_3_torch.py:278-286).  wh [n,2], anchors [k,2] in
  * the same units, k <= 64 -> assign [n] = argmax_j shape-IoU (ties -> lowest j), best_iou [n] (may be NULL). */

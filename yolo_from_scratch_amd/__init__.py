@@ -8,3 +8,4 @@ from .loss import YoloV1Loss, MSELoss  # noqa: F401
 from .assign import assign_targets_v2, VOC_ANCHORS  # noqa: F401
 from .anchors import estimate_size_priors, kmeans_anchors, anchor_assign  # noqa: F401
 from .metrics import mean_average_precision  # noqa: F401
+from .data import mask_to_boxes, box_to_xywh_norm, largest_box, mask_to_target_box, encode_targets_v1  # noqa: F401

@@ -120,6 +120,62 @@ __global__ void __launch_bounds__(kThreads) assign_v2_kernel(const float* __rest
     unstage_floats(targets + n * (int64_t)per * 5, per * 5, tstage, tid);
 }
 
+
+// YOLOv1 grid targets from ground-truth boxes (the step between the reference's
+// box_to_xywh_norm, yolo_toy_regressor_torch.py:113-119, and the composite loss).  One workgroup per image; one
+// thread per gt slot finds its cell, the lowest gt index that maps to a cell owns it (same rule as the YOLOv2
+// assignment), the owner writes (x offset, y offset, w, h, 1) into box slot 0 and the one-hot class.  The image's
+// target is zero-filled by the whole workgroup first (16-byte stores), owners write after a barrier.
+__global__ void __launch_bounds__(kThreads) encode_targets_v1_kernel(const float* __restrict__ gt, int G, int S, int B, int C,
+                                                                    float* __restrict__ target) {
+    extern __shared__ int cell_of[];   // [G]: cell index or -1
+    const int64_t n = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int D = 5 * B + C, len = S * S * D;
+    float* t = target + n * (int64_t)len;
+    {   // zero fill: t is only 4-byte aligned in general
+        const int dskew = (int)((reinterpret_cast<uintptr_t>(t) >> 2) & 3);
+        const int head = ((4 - dskew) & 3) < len ? ((4 - dskew) & 3) : len;
+        if (tid < head) t[tid] = 0.0f;
+        const int nq = (len - head) >> 2;
+        float4* t4 = reinterpret_cast<float4*>(t + head);
+        for (int q = tid; q < nq; q += kThreads) t4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int done = head + nq * 4;
+        if (tid < len - done) t[done + tid] = 0.0f;
+    }
+    const float* g = gt + n * (int64_t)G * 5;
+    for (int i = tid; i < G; i += kThreads) {
+        int cell = -1;
+        if (g[i * 5 + 2] > 0.0f) {   // w <= 0 marks padding
+            int col = (int)floorf(g[i * 5 + 0] * (float)S), row = (int)floorf(g[i * 5 + 1] * (float)S);
+            col = col < S - 1 ? col : S - 1;
+            row = row < S - 1 ? row : S - 1;
+            col = col > 0 ? col : 0;
+            row = row > 0 ? row : 0;
+            cell = row * S + col;
+        }
+        cell_of[i] = cell;
+    }
+    __syncthreads();   // also orders the zero fill before the owners' stores (same workgroup, global memory)
+    __threadfence_block();
+    for (int i = tid; i < G; i += kThreads) {
+        const int cell = cell_of[i];
+        if (cell < 0) continue;
+        bool owner = true;
+        for (int j = 0; j < i; ++j) owner = owner && cell_of[j] != cell;
+        if (!owner) continue;
+        const int row = cell / S, col = cell - row * S;
+        float* o = t + (int64_t)cell * D;
+        o[0] = g[i * 5 + 0] * (float)S - (float)col;
+        o[1] = g[i * 5 + 1] * (float)S - (float)row;
+        o[2] = g[i * 5 + 2];
+        o[3] = g[i * 5 + 3];
+        o[4] = 1.0f;
+        const int c = (int)g[i * 5 + 4];
+        if (c >= 0 && c < C) o[5 * B + c] = 1.0f;
+    }
+}
+
 }  // namespace
 
 // k-means anchor clustering, assignment step (README.md:56 "k-means or VOC defaults"; SPEC.md §6): every box
@@ -180,5 +236,15 @@ YFS_API int yfs_assign_targets_v2_f32(const float* gt, int64_t N, int G, int S, 
     assign_v2_kernel<<<dim3((unsigned)N), dim3(kThreads), lds, (hipStream_t)stream>>>(
         gt, G, S, A, anchors, (const float4*)pred_boxes, ignore_thr, obj_mask, ignore_mask, targets);
     YFS_CHECK_LAUNCH("assign_v2_kernel");
+    return YFS_OK;
+}
+
+YFS_API int yfs_encode_targets_v1_f32(const float* gt, int64_t N, int G, int S, int B, int C, float* target, void* stream) {
+    YFS_REQUIRE(gt && target, YFS_ERR_INVALID_ARG, "yfs_encode_targets_v1_f32: null pointer");
+    YFS_REQUIRE(N > 0 && G > 0 && G <= 4096 && S > 0 && B > 0 && C > 0, YFS_ERR_INVALID_ARG,
+                "yfs_encode_targets_v1_f32: bad shape N=%lld G=%d S=%d B=%d C=%d", (long long)N, G, S, B, C);
+    encode_targets_v1_kernel<<<dim3((unsigned)N), dim3(kThreads), (size_t)G * sizeof(int), (hipStream_t)stream>>>(gt, G, S, B, C,
+                                                                                                                target);
+    YFS_CHECK_LAUNCH("encode_targets_v1_kernel");
     return YFS_OK;
 }

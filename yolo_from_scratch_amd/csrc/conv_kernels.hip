@@ -963,6 +963,8 @@ WgradPlan plan_wgrad(int64_t M, int Cin, int Cout, int taps, bool wide192 = fals
         const double t = (double)rounds * (per * t_tile + 3.0) + real * t_slab;
         if (t < best) { best = t; best_per = per; }
     }
+    static const int force_splits = [] { const char* e = getenv("YFS_WGRAD_SPLITS"); return e ? atoi(e) : 0; }();   // sweeps
+    if (force_splits > 0) best_per = (int)yfs_cdiv(p.ktiles, force_splits < p.ktiles ? force_splits : p.ktiles);
     p.ktiles_per_split = best_per;
     p.splits = (int)yfs_cdiv(p.ktiles, p.ktiles_per_split);
     p.partial_bytes = (size_t)p.splits * Cout * taps * Cin * sizeof(float);
