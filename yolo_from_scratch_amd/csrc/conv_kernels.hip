@@ -423,7 +423,7 @@ int dispatch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
         // round in 4u / 1.18 (its measured per-CU advantage); take the big tile when that wins by >= 10 %.
         const long long t128 = yfs_cdiv(g.M, 128) * (g.NOUT / 128), t256 = yfs_cdiv(g.M, 256) * yfs_cdiv(g.NOUT, 256);
         const double c128 = (double)yfs_cdiv(t128, 512) * 2.0, c256 = (double)yfs_cdiv(t256, 256) * (4.0 / 1.18);
-        big = c256 < 0.9 * c128 && g.KH * g.KW * g.C >= 2304;
+        big = c256 < 0.9 * c128 && g.KH * g.KW * g.C >= 1728;   // (shorter K: the four-pass epilogue eats the gain)
     }
     if (big && g.NOUT % 256 == 0) return launch_igemm<256, 256, 2, 4, 2, EPI, SUB>(g, s, name);
     return launch_igemm<128, 128, 2, 2, 2, EPI, SUB>(g, s, name);
