@@ -409,7 +409,8 @@ int launch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
 // 3 stages (875-990), 32-deep rings at four workgroups per CU (790-880), 32-deep 4/5-stage rings (780-870),
 // 256x128 / 4 waves / 32-deep (810-980), issuing the loads between the MFMAs instead of in a burst (-6 %),
 // 256x256 / 4 waves of 128x128 at one wave per SIMD with all 256 AGPRs as accumulators (the vendor GEMM's shape;
-// compiles without spills but the compiler's schedule leaves the single wave exposed: 730-890).
+// compiles without spills but the compiler's schedule leaves the single wave exposed: 730-890), 256x192 / 8 waves for
+// the 192-channel outputs (stem + pool 584 vs 571 us, feat.2 dgrad 759 vs 738 us: no gain).
 // 128x192 serves the 192-channel outputs (pixel tile read once instead of three times with 128x64).  YFS_IGEMM_TILE=128|256|2562 forces a variant for benchmarking.
 template <int EPI, bool SUB>
 int dispatch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
