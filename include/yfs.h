@@ -217,6 +217,19 @@ int yfs_sumsq_f32(const float *g, int64_t n, float *sumsq_out, void *workspace, 
 int yfs_sgd_step_f32(float *p, const float *g, float *buf, int64_t n, const float *sumsq, float max_norm,
                      float lr, float momentum, float weight_decay, int first_step, void *p_bf16, void *stream);
 
+/* Linear layer, weight gradient fused with the optimiser step (fc.1 = nn.Linear(50176, 4096),
+ * yolo_toy_regressor_torch.py:259; its backward at :330 and the update at :331-335, :378-381).
+ * x [B,In] bf16 (the layer's input), dy [B,Out] bf16 (gradient of its output); the weight p [Out,In] fp32, its
+ * momentum buffer m and bf16 shadow p_bf16 (may be NULL) are updated in place with
+ *   g = grad_scale * sum_b dy[b][o] * x[b][i];  clip = min(1, max_norm / (sqrt(*sumsq) + 1e-6)) (1 when sumsq == NULL
+ *   or max_norm <= 0);  d = clip*g + wd*p;  m = first_step ? d : momentum*m + d;  p -= lr*m
+ * exactly as yfs_sgd_step_f32 would with a materialised gradient — which is never written (4 B/parameter less to
+ * write, to sum and to re-read).  *sumsq must already hold the squared gradient norm of the WHOLE model including
+ * this layer's own (||dy^T x||_F^2 = sum((dy dy^T) * (x x^T)), two B x B Gram matrices).  In, Out multiples of 128. */
+int yfs_linear_wgrad_sgd_bf16(const void *x, const void *dy, int64_t B, int In, int Out, float *p, float *m, void *p_bf16,
+                              const float *sumsq, float max_norm, float lr, float momentum, float weight_decay,
+                              int first_step, float grad_scale, void *stream);
+
 /* YOLOv1 grid targets from ground-truth boxes: the step between the reference's data path (largest mask box ->
  * box_to_xywh_norm, yolo_toy_regressor_torch.py:98-119, :184-203) and the composite loss (SPEC.md 1; the grid
  * encoding itself has no reference code, README.md:90-93 gives the convention).  gt [N,G,5] = (xc, yc, w, h, class)

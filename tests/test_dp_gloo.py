@@ -42,6 +42,25 @@ def test_bucket_layout_reverse_order_and_coverage():
     assert len(comm.buckets) >= 2
 
 
+def test_bucket_layout_skips_deferred_parameters():
+    """A parameter whose gradient is never materialised (FlatSGD's deferred Linear weight) belongs to no bucket and
+    no bucket spans its slice of the arena."""
+    offs, total = _layout()
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in SHAPES]
+    comm = dp.GradComm(world_size=2, bucket_bytes=1 << 30)            # one bucket if nothing were skipped
+    skipped = params[4]                                                # the (1000, 300) "fc" weight
+    comm.attach(params, offs, torch.zeros(total), skip_ids={id(skipped)})
+    assert id(skipped) not in comm.param_bucket
+    lo_s, n_s = offs[4]
+    for lo, hi in comm.buckets:
+        assert hi <= lo_s or lo >= lo_s + n_s
+    assert len(comm.buckets) == 2
+    for p, (off, n) in zip(params, offs):
+        if p is not skipped:
+            lo, hi = comm.buckets[comm.param_bucket[id(p)]]
+            assert lo <= off and off + n <= hi
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -68,6 +87,13 @@ def _worker(rank, world, port, q):
             expect = sum(others) / world
             for off, n in offs:
                 np.testing.assert_allclose(flat_g[off:off + n].numpy(), expect[off:off + n].numpy(), rtol=1e-6, atol=1e-7)
+        # factors of a deferred Linear gradient: gathered in rank order, so sum_r dy_r^T x_r = DY^T X
+        x = torch.full((3, 8), float(rank + 1)).bfloat16()
+        dy = torch.full((3, 4), float(10 * (rank + 1))).bfloat16()
+        xa, da = comm.gather_factors(x, dy)
+        assert xa.shape == (3 * world, 8) and da.shape == (3 * world, 4)
+        for r in range(world):
+            assert float(xa[3 * r, 0]) == r + 1 and float(da[3 * r + 2, 3]) == 10 * (r + 1)
         q.put((rank, "ok"))
     except Exception as e:   # noqa: BLE001
         q.put((rank, repr(e)))

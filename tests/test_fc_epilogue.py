@@ -96,3 +96,32 @@ def test_fused_linear_module_train_eval_and_gradients():
     gb = ((y_ref > 0).float() + (y_ref <= 0).float() * 0.1) * kept.float() / 0.75
     np.testing.assert_allclose(lin.bias.grad.cpu().numpy(), gb.sum(0).numpy(), rtol=2e-2, atol=2e-2)
     assert xg.grad is not None and torch.isfinite(xg.grad).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,n_in,n_out,first,clip", [(64, 512, 256, True, False), (64, 1280, 384, False, True),
+                                                     (20, 256, 128, False, False), (130, 384, 256, False, True)])
+def test_linear_wgrad_fused_with_sgd_step(b, n_in, n_out, first, clip):
+    """yfs_linear_wgrad_sgd_bf16 == (dW = dy^T x in fp32 from the bf16 operands) followed by the clip + SGD formula of
+    yolo_toy_regressor_torch.py:331-335, :378-381, to fp32 summation-order tolerance; the bf16 shadow is the rounding of
+    the updated weight."""
+    from yolo_from_scratch_amd import fc_ops as fo
+    g = torch.Generator().manual_seed(b + n_in)
+    x = torch.randn(b, n_in, generator=g).bfloat16()
+    dy = (torch.randn(b, n_out, generator=g) * 0.1).bfloat16()
+    p = torch.randn(n_out, n_in, generator=g)
+    m = torch.randn(n_out, n_in, generator=g) * 0.01
+    lr, mom, wd, max_norm, gs = 1e-2, 0.9, 5e-4, 1.0, 0.5
+    gw = gs * (dy.double().t() @ x.double())
+    sumsq = torch.tensor([float((gw ** 2).sum()) + 3.0])          # "+3": the rest of the model
+    coef = min(1.0, max_norm / (float(sumsq.sqrt()) + 1e-6)) if clip else 1.0
+    d = gw * coef + wd * p.double()
+    m_ref = d if first else mom * m.double() + d
+    p_ref = p.double() - lr * m_ref
+    pd, md = p.to(DEV).clone(), m.to(DEV).clone()
+    p16 = torch.zeros(n_out, n_in, device=DEV, dtype=torch.bfloat16)
+    fo.linear_wgrad_sgd(x.to(DEV), dy.to(DEV), pd, md, p16, sumsq.to(DEV) if clip else None, max_norm if clip else 0.0, lr, mom,
+                        wd, first, gs)
+    np.testing.assert_allclose(md.cpu().numpy(), m_ref.float().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(pd.cpu().numpy(), p_ref.float().numpy(), rtol=1e-5, atol=1e-6)
+    assert torch.equal(p16, pd.bfloat16())

@@ -266,3 +266,71 @@ def test_fit_epoch_loop_checkpoint_and_log(tmp_path):
         assert torch.equal(v.cpu().contiguous(), sd[k]), k
     w = net.feat[2][0].weight
     assert torch.equal(yt.bf16_shadow(w).float(), w.detach().to(torch.bfloat16).float())
+
+
+def test_deferred_linear_gradient_step_equals_materialised(monkeypatch):
+    """FlatSGD takes a large Linear weight's step from (x, dy) in one fused kernel (no materialised gradient); the
+    trajectory must equal the materialised path (YFS_DEFER_FC=0) to fp32 summation-order tolerance, with clipping
+    active, over several steps, and when two backward passes precede one step (accumulation falls back)."""
+    def build(defer):
+        monkeypatch.setenv("YFS_DEFER_FC", "1" if defer else "0")
+        torch.manual_seed(11)
+        net = nn.Sequential(ym.HipLinear(8192, 2048), nn.LeakyReLU(0.1), ym.HipLinear(2048, 64)).to(DEV)
+        opt = yt.FlatSGD(net.parameters(), lr=5e-2, momentum=0.9, weight_decay=5e-4, max_norm=0.5)
+        return net, opt
+    (na, oa), (nb, ob) = build(True), build(False)
+    assert getattr(na[0].weight, "_yfs_defer", False) and not getattr(nb[0].weight, "_yfs_defer", False)
+    assert not getattr(na[2].weight, "_yfs_defer", False)           # small layer: ordinary gradient
+    g = torch.Generator().manual_seed(5)
+    for step in range(4):
+        x = torch.randn(32, 8192, generator=g).to(DEV)
+        for net, opt in ((na, oa), (nb, ob)):
+            opt.zero_grad()
+            net(x).float().pow(2).mean().backward()
+            if step == 2:                                             # second backward before the step
+                net(x * 0.5).float().pow(2).mean().backward()
+            opt.step()
+        if step < 2:
+            assert float(na[0].weight.grad.abs().max()) == 0.0       # documented: not materialised in deferred mode
+    for pa, pb in zip(na.parameters(), nb.parameters()):
+        assert _rel(pa, pb) < 2e-5
+    assert _rel(oa.flat_m, ob.flat_m) < 2e-5
+    assert torch.equal(oa.flat_p16, oa.flat_p.bfloat16())
+
+
+def test_deferred_linear_gradient_under_data_parallel_exchange(monkeypatch):
+    """The N>1 form of the deferred step on one GPU: a GradComm of world size 2 whose collectives are replaced by
+    what they return when both ranks hold the same data (all_gather = two copies, all_reduce SUM = x2).  The mean
+    gradient then equals the single-process gradient, so the trajectory must match a run without any exchange; this
+    drives the bucket layout that skips the deferred weight, the factor gather on the exchange stream, the
+    2B-row fused kernel with grad_scale = 1/2 and the Gram-matrix norm with that scale."""
+    from yolo_from_scratch_amd import dp
+    world = 2
+
+    def fake_all_gather(outs, t, group=None):
+        for o in outs:
+            o.copy_(t)
+
+    def fake_all_reduce(t, op=None, group=None):
+        t.mul_(world)
+    monkeypatch.setattr(dp.dist, "all_gather", fake_all_gather)
+    monkeypatch.setattr(dp.dist, "all_reduce", fake_all_reduce)
+
+    def build(comm):
+        torch.manual_seed(21)
+        net = nn.Sequential(ym.HipLinear(8192, 2048), nn.LeakyReLU(0.1), ym.HipLinear(2048, 64)).to(DEV)
+        return net, yt.FlatSGD(net.parameters(), lr=5e-2, momentum=0.9, weight_decay=5e-4, max_norm=0.5, comm=comm)
+    comm = dp.GradComm(world, bucket_bytes=1 << 20)
+    (na, oa), (nb, ob) = build(comm), build(None)
+    assert na[0].weight._yfs_defer and id(na[0].weight) not in comm.param_bucket
+    g = torch.Generator().manual_seed(6)
+    for _ in range(3):
+        x = torch.randn(32, 8192, generator=g).to(DEV)
+        for net, opt in ((na, oa), (nb, ob)):
+            opt.zero_grad()
+            net(x).float().pow(2).mean().backward()
+            opt.step()
+    torch.cuda.synchronize()
+    for pa, pb in zip(na.parameters(), nb.parameters()):
+        assert _rel(pa, pb) < 2e-5
+    assert _rel(oa.flat_m, ob.flat_m) < 2e-5

@@ -535,6 +535,14 @@ struct WgradArgs {
     // advances kh_mul input rows.
     unsigned xgroup_bytes;   // 128 = contiguous
     int kh_mul;              // 1 normally
+    // SGD epilogue (wgrad_kernel<..., SGD = true>): the tile of dw never leaves the CU — it is the gradient of the
+    // optimiser step applied to the same tile of the fp32 master weight, momentum buffer and bf16 shadow in place.
+    float* sgd_p;
+    float* sgd_m;
+    bf16_t* sgd_p16;          // may be null
+    const float* sgd_sumsq;   // total squared gradient norm of the whole model (device scalar), or null = no clipping
+    float sgd_max_norm, sgd_lr, sgd_momentum, sgd_wd, sgd_gscale;
+    int sgd_first;
     unsigned xbytes, zbytes;
     int cotiles, citiles, splits, ktiles, ktiles_per_split;
     FastDiv div_ohw, div_ow;
@@ -562,7 +570,7 @@ __device__ __forceinline__ unsigned wg_addr(int pixel, int ch /* channel inside 
 // dz tensor that pool backward would have to write first (3/4 zeros), the dz tile is built in LDS from the pooled
 // gradient, the pool's 2-bit argmax record and the pooled activation (LeakyReLU derivative).  The reduction then
 // enumerates output pixels window-major (m = 4 * window + position) so that one window is four consecutive rows.
-template <int BX, int BZ, bool POOLZ>
+template <int BX, int BZ, bool POOLZ, bool SGD = false>
 __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
     constexpr int FX = BX / 32, FZ = BZ / 32;          // fragments per wave
     constexpr int CX = BX / 8, CZ = BZ / 8;            // 16-byte chunks per pixel row
@@ -847,6 +855,58 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
 
     // acc[a][b][r] = dw[co = co0 + wz*BZ/2 + b*16 + (lane&15)][tap][ci = ci0 + wx*BX/2 + a*16 + (lane>>4)*4 + r]
     const long long kw_tot = (long long)taps * g.Cin;
+    if constexpr (SGD) {
+        // fp32 tile -> LDS ([BZ rows][BX floats], 16-byte slots XOR-swizzled by the row so that neither the fragment
+        // writes nor the row reads conflict; exactly the 64 KiB of the operand ring, free after the last barrier),
+        // then every thread streams float4 columns of whole rows: p, m read and written once, coalesced.
+        static_assert(BX == 128 && BZ == 128, "SGD epilogue is instantiated for the 128x128 tile");
+#pragma unroll
+        for (int a = 0; a < FX; ++a)
+#pragma unroll
+            for (int b = 0; b < FZ; ++b) {
+                const int row = wz * (BZ / 2) + b * 16 + li;
+                const int c4 = (wx * (BX / 2) + a * 16 + g4 * 4) >> 2;
+                *reinterpret_cast<f32x4*>(smem + row * (BX * 4) + ((c4 ^ (row & 31)) << 4)) = acc[a][b];
+            }
+        __syncthreads();
+        float coef = g.sgd_gscale;
+        if (g.sgd_sumsq && g.sgd_max_norm > 0.0f) {
+            const float c = g.sgd_max_norm / (sqrtf(g.sgd_sumsq[0]) + 1e-6f);   // clip_grad_norm_ (as sgd_kernel)
+            coef *= c < 1.0f ? c : 1.0f;
+        }
+        const int c4 = tid & 31, r0 = tid >> 5;
+        constexpr int UN = 4;
+#pragma unroll 1
+        for (int sw = 0; sw < BZ / 8; sw += UN) {
+            f32x4 pv[UN], mv[UN], gv[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {   // all loads of the batch in flight before the first use
+                const int row = (sw + u) * 8 + r0;
+                const long long e = (long long)(co0 + row) * kw_tot + ci0 + c4 * 4;
+                pv[u] = *reinterpret_cast<const f32x4*>(g.sgd_p + e);
+                if (!g.sgd_first) mv[u] = *reinterpret_cast<const f32x4*>(g.sgd_m + e);
+                gv[u] = *reinterpret_cast<const f32x4*>(smem + row * (BX * 4) + ((c4 ^ (row & 31)) << 4));
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int row = (sw + u) * 8 + r0;
+                const long long e = (long long)(co0 + row) * kw_tot + ci0 + c4 * 4;
+                f32x4 bo, po;
+                bf16x4 ps;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float d = gv[u][r] * coef + g.sgd_wd * pv[u][r];
+                    bo[r] = g.sgd_first ? d : g.sgd_momentum * mv[u][r] + d;
+                    po[r] = pv[u][r] - g.sgd_lr * bo[r];
+                    ps[r] = (bf16_t)po[r];
+                }
+                *reinterpret_cast<f32x4*>(g.sgd_m + e) = bo;
+                *reinterpret_cast<f32x4*>(g.sgd_p + e) = po;
+                if (g.sgd_p16) *reinterpret_cast<bf16x4*>(g.sgd_p16 + e) = ps;
+            }
+        }
+        return;
+    }
     float* pbase = g.partial + (long long)split * g.Cout * kw_tot;
 #pragma unroll
     for (int a = 0; a < FX; ++a)
@@ -974,10 +1034,10 @@ WgradPlan plan_wgrad(int64_t M, int Cin, int Cout, int taps, bool wide192 = fals
     return p;
 }
 
-template <int BX, int BZ, bool POOLZ = false>
+template <int BX, int BZ, bool POOLZ = false, bool SGD = false>
 int launch_wgrad(WgradArgs& g, const WgradPlan& p, hipStream_t s) {
     const size_t lds = 2 * (size_t)(BX + BZ) * 128;
-    auto kern = wgrad_kernel<BX, BZ, POOLZ>;
+    auto kern = wgrad_kernel<BX, BZ, POOLZ, SGD>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         YFS_REQUIRE(e == hipSuccess, YFS_ERR_LAUNCH, "yfs_conv2d_wgrad_bf16: cannot reserve %zu bytes of LDS", lds);
@@ -1068,6 +1128,33 @@ YFS_API int yfs_conv2d_wgrad_bf16(const void* x, const void* dz, float* dw, floa
     const int OH = (H + 2 * pad - K) / stride + 1, OW = (W + 2 * pad - K) / stride + 1;
     return wgrad_common("yfs_conv2d_wgrad_bf16", x, dz, dw, db, N, H, W, Cin, Cin, OH, OW, Cout, K, K, stride, pad, accumulate,
                         workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// ---- Linear layer: weight gradient fused with the optimiser step ---------------------------------------------------
+// dW[o][i] = sum_b dy[b][o] * x[b][i] is the 1x1 "convolution" wgrad over B pixels; with the SGD epilogue the
+// 4 B/parameter gradient is never written, summed or re-read (fc.1: 822 MB each).
+YFS_API int yfs_linear_wgrad_sgd_bf16(const void* x, const void* dy, int64_t B, int In, int Out, float* p, float* m, void* p_bf16,
+                                      const float* sumsq, float max_norm, float lr, float momentum, float weight_decay,
+                                      int first_step, float grad_scale, void* stream) {
+    YFS_REQUIRE(x && dy && p && m, YFS_ERR_INVALID_ARG, "yfs_linear_wgrad_sgd_bf16: null pointer");
+    YFS_REQUIRE(B > 0 && In > 0 && Out > 0 && In % 128 == 0 && Out % 128 == 0, YFS_ERR_UNSUPPORTED,
+                "yfs_linear_wgrad_sgd_bf16: In=%d and Out=%d must be positive multiples of 128 (B=%lld)", In, Out, (long long)B);
+    YFS_REQUIRE(B * In * 2 < 0xFFF00000ll && B * Out * 2 < 0xFFF00000ll, YFS_ERR_UNSUPPORTED,
+                "yfs_linear_wgrad_sgd_bf16: an operand exceeds the 4 GiB range of one buffer descriptor");
+    WgradArgs g = {};
+    g.dz = (const bf16_t*)dy; g.x = (const bf16_t*)x;
+    g.H = 1; g.W = 1; g.Cin = In; g.OH = 1; g.OW = 1; g.Cout = Out; g.KH = 1; g.KW = 1; g.PS = In; g.stride = 1; g.pad = 0;
+    g.M = (int)B;
+    g.xgroup_bytes = 128; g.kh_mul = 1;
+    g.xbytes = (unsigned)(B * In * 2); g.zbytes = (unsigned)(B * Out * 2);
+    WgradPlan pl = {};
+    pl.bx = pl.bz = 128; pl.citiles = In / 128; pl.cotiles = Out / 128; pl.ktiles = (int)yfs_cdiv(B, 64);
+    pl.splits = 1; pl.ktiles_per_split = pl.ktiles;
+    g.cotiles = pl.cotiles; g.citiles = pl.citiles; g.splits = 1; g.ktiles = pl.ktiles; g.ktiles_per_split = pl.ktiles;
+    g.div_ohw = make_fastdiv(1u); g.div_ow = make_fastdiv(1u);
+    g.sgd_p = p; g.sgd_m = m; g.sgd_p16 = (bf16_t*)p_bf16; g.sgd_sumsq = sumsq; g.sgd_max_norm = max_norm; g.sgd_lr = lr;
+    g.sgd_momentum = momentum; g.sgd_wd = weight_decay; g.sgd_gscale = grad_scale; g.sgd_first = first_step;
+    return launch_wgrad<128, 128, false, true>(g, pl, (hipStream_t)stream);
 }
 
 // ---- stem: Conv2D(3, Cout, 7, s=2) as a 4x4 stride-1 convolution over the 2x2 space-to-depth image ------------

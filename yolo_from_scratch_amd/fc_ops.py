@@ -35,3 +35,20 @@ def fc_epilogue_bwd(dy, y, keep, slope=0.1, p_drop=0.0, db=None, accumulate=Fals
                                              L.c_float(slope), L.c_float(p_drop), L.c_int(1 if accumulate else 0), L.stream()),
             "yfs_fc_epilogue_bwd_bf16")
     return dz
+
+
+def linear_wgrad_sgd(x16, dy16, p, m, p16, sumsq, max_norm, lr, momentum, weight_decay, first_step, grad_scale=1.0):
+    """Weight gradient of a Linear layer fused with its SGD step (include/yfs.h: yfs_linear_wgrad_sgd_bf16): p [Out,In]
+    fp32, m (momentum) and p16 (bf16 shadow, may be None) are updated in place from x16 [B,In], dy16 [B,Out]; ``sumsq``
+    = device scalar with the whole model's squared gradient norm (None = no clipping)."""
+    L.require_cuda(x16, dy16, p, m)
+    if x16.dtype != torch.bfloat16 or dy16.dtype != torch.bfloat16 or not (x16.is_contiguous() and dy16.is_contiguous()):
+        raise L.YfsError("linear_wgrad_sgd: x and dy must be contiguous bf16")
+    b, n_in = x16.shape
+    n_out = dy16.shape[1]
+    if dy16.shape[0] != b or tuple(p.shape) != (n_out, n_in) or not p.is_contiguous() or p.dtype != torch.float32:
+        raise L.YfsError("linear_wgrad_sgd: shape / layout mismatch")
+    L.check(L.lib().yfs_linear_wgrad_sgd_bf16(L.ptr(x16), L.ptr(dy16), L.i64(b), L.c_int(n_in), L.c_int(n_out), L.ptr(p), L.ptr(m),
+                                              L.ptr(p16), L.ptr(sumsq), L.c_float(max_norm or 0.0), L.c_float(lr),
+                                              L.c_float(momentum), L.c_float(weight_decay), L.c_int(1 if first_step else 0),
+                                              L.c_float(grad_scale), L.stream()), "yfs_linear_wgrad_sgd_bf16")

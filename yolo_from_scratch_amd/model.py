@@ -447,6 +447,30 @@ class _LinearFn(torch.autograd.Function):
             dy16 = dy.to(torch.bfloat16).contiguous()
         dx = torch.mm(dy16, w16).to(ctx.in_dtype) if ctx.needs_input_grad[0] else None
 
+        sink_w = getattr(weight, "_yfs_grad_sink", None)
+        pending = getattr(weight, "_yfs_factors", None)
+        comm = getattr(weight, "_yfs_comm", None)
+        multi = comm is not None and getattr(comm, "world", 1) > 1
+        if pending is not None and sink_w is not None:
+            # a second backward before the step: the deferred factors become an ordinary gradient first
+            if multi:
+                raise L.YfsError("several backward passes per step are not supported together with the deferred Linear "
+                                 "gradient under data parallelism (set YFS_DEFER_FC=0)")
+            torch.mm(pending[1].t(), pending[0], out_dtype=torch.float32, out=sink_w)
+            weight._yfs_factors = None
+        elif getattr(weight, "_yfs_defer", False) and sink_w is not None and weight._yfs_grad_fresh:
+            # FlatSGD takes this layer's step from the factors of its gradient (train.FlatSGD._step_with_deferred);
+            # with several ranks the factors of all ranks are gathered and the mean gradient is 1/world of their product
+            if multi:
+                xa, da = comm.gather_factors(x16, dy16)
+                weight._yfs_factors = (xa, da, 1.0 / comm.world)
+            else:
+                weight._yfs_factors = (x16, dy16, 1.0)
+            weight._yfs_grad_fresh = False
+            db = db_fused[0] if db_fused is not None else write_grad(bias, lambda sink, acc: _bias_grad(dy16, sink, acc))
+            ctx.wb = ctx.w16 = None
+            return dx, None, db, None, None, None
+
         def put_w(sink, acc):     # bf16 operands, fp32 result straight into the gradient arena (no bf16 round trip)
             if sink is None or acc:
                 dw = torch.mm(dy16.t(), x16, out_dtype=torch.float32)
@@ -467,6 +491,13 @@ class _LinearFn(torch.autograd.Function):
         return dx, dw, db, None, None, None
 
 
+def _bias_grad(dy16, sink, acc):
+    db = dy16.float().sum(0)
+    if sink is None:
+        return db
+    sink.add_(db) if acc else sink.copy_(db)
+
+
 class HipLinear(nn.Linear):
     """nn.Linear with the same parameter names/init; bf16 compute, fp32 master weights.
     ``fused_act`` = slope: the LeakyReLU(slope) that follows the layer (and the Dropout module handed to
@@ -476,6 +507,9 @@ class HipLinear(nn.Linear):
     def __init__(self, in_features, out_features, fused_act=None):
         super().__init__(in_features, out_features)
         self.weight._yfs_sink_capable = self.bias._yfs_sink_capable = True
+        # big enough that skipping the materialised gradient pays (see train.FlatSGD): fc.1 yes, fc.4 no
+        self.weight._yfs_defer_capable = (in_features % 128 == 0 and out_features % 128 == 0 and
+                                          in_features * out_features >= (1 << 24))
         self.fused_act = fused_act
         self.__dict__["_drop_ref"] = None       # not a submodule: keeps the key names of the reference
 
