@@ -358,7 +358,9 @@ def main():
             "config": {"workload": "YOLOv1 448x448 S=7 B=2 C=20 train step, per-GPU batch %d, bf16 conv MFMA + fused "
                                    "composite loss + clip + SGD (BASELINE configs[1]; configs[2] when n_gpus=8)" % args.batch,
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "grad_allreduce": ("bf16" if args.compress_bf16 else "fp32") if world > 1 else None},
+                       "grad_allreduce": (("bf16" if args.compress_bf16 else "fp32") +
+                                          (" buckets; fc.1 as all-gathered gradient factors" if opt._defer else ""))
+                       if world > 1 else None},
             "final_loss": round(final_loss, 5),
             "roofline": {"bound": "mfma", "kernel": "conv implicit-GEMM set (igemm_kernel fwd+dgrad, wgrad_kernel)",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
