@@ -926,14 +926,55 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
 // dw[i] = (accumulate ? dw[i] : 0) + sum_s partial[s][i].  G groups of threads share one float4 column: group r
 // sums slabs r, r+G, ... and the G sums are combined through LDS in fixed order (deterministic).  Small outputs
 // with many slabs (1x1 layers: 32K floats x 224 slabs) would otherwise run on a few dozen serial threads.
+// db[c] = (accumulate ? db[c] : 0) + sum of the wgrad kernel's partial column-sum rows.  One block per 16
+// channels; 16 row groups (rows r, r+16, ...) per channel are summed independently and combined in fixed order.
+__device__ __forceinline__ void colsum_reduce_block(const float* __restrict__ partial, int nsplit, int C, float* __restrict__ db,
+                                                    int accumulate, int blk, float (*red)[16 + 1]) {
+    const int cl = threadIdx.x & 15, r = threadIdx.x >> 4;
+    const int c = blk * 16 + cl;
+    float s = 0.f;
+    if (c < C) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // four loads in flight; combined in fixed order
+        int k = r;
+        for (; k + 48 < nsplit; k += 64) {
+            s0 += partial[(long long)k * C + c];
+            s1 += partial[(long long)(k + 16) * C + c];
+            s2 += partial[(long long)(k + 32) * C + c];
+            s3 += partial[(long long)(k + 48) * C + c];
+        }
+        for (; k < nsplit; k += 16) s0 += partial[(long long)k * C + c];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    red[r][cl] = s;
+    __syncthreads();
+    if (r == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][cl];
+        db[c] = accumulate ? db[c] + t : t;
+    }
+}
+
+// dw[i] = (accumulate ? dw[i] : 0) + sum_s partial[s][i].  G groups of threads share one float4 column: group r
+// sums slabs r, r+G, ... and the G sums are combined through LDS in fixed order (deterministic).  Small outputs
+// with many slabs (1x1 layers: 32K floats x 224 slabs) would otherwise run on a few dozen serial threads.
+// The blocks past `nblk_main` reduce the bias-gradient rows (colsum_reduce_block) in the same launch: both reductions
+// are a few microseconds of work and a launch each was as long as the work itself, 24 times per step.
 template <int G>
 __global__ void __launch_bounds__(kThreads) splitk_reduce_kernel(const float4* __restrict__ partial, int splits,
                                                                  long long n4, float4* __restrict__ dw,
-                                                                 int accumulate) {
+                                                                 int accumulate, int nblk_main,
+                                                                 const float* __restrict__ dbpart, int db_splits, int C,
+                                                                 float* __restrict__ db) {
     constexpr int COLS = kThreads / G;
     __shared__ float4 red[G][COLS];
+    __shared__ float cred[16][16 + 1];
+    if ((int)blockIdx.x >= nblk_main) {
+        colsum_reduce_block(dbpart, db_splits, C, db, accumulate, (int)blockIdx.x - nblk_main, cred);
+        return;
+    }
     const int cl = threadIdx.x % COLS, r = threadIdx.x / COLS;
-    for (long long i0 = (long long)blockIdx.x * COLS; i0 < n4; i0 += (long long)gridDim.x * COLS) {
+    for (long long i0 = (long long)blockIdx.x * COLS; i0 < n4; i0 += (long long)nblk_main * COLS) {
         const long long i = i0 + cl;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < n4)
@@ -960,36 +1001,6 @@ __global__ void __launch_bounds__(kThreads) splitk_reduce_kernel(const float4* _
             }
             dw[i] = s;
         }
-    }
-}
-
-// db[c] = (accumulate ? db[c] : 0) + sum of the wgrad kernel's partial column-sum rows.  One block per 16
-// channels; 16 row groups (rows r, r+16, ...) per channel are summed independently and combined in fixed order.
-__global__ void __launch_bounds__(kThreads) colsum_reduce_kernel(const float* __restrict__ partial, int nsplit, int C,
-                                                                 float* __restrict__ db, int accumulate) {
-    __shared__ float red[16][16 + 1];
-    const int cl = threadIdx.x & 15, r = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
-    float s = 0.f;
-    if (c < C) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // four loads in flight; combined in fixed order
-        int k = r;
-        for (; k + 48 < nsplit; k += 64) {
-            s0 += partial[(long long)k * C + c];
-            s1 += partial[(long long)(k + 16) * C + c];
-            s2 += partial[(long long)(k + 32) * C + c];
-            s3 += partial[(long long)(k + 48) * C + c];
-        }
-        for (; k < nsplit; k += 16) s0 += partial[(long long)k * C + c];
-        s = (s0 + s1) + (s2 + s3);
-    }
-    red[r][cl] = s;
-    __syncthreads();
-    if (r == 0 && c < C) {
-        float t = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) t += red[k][cl];
-        db[c] = accumulate ? db[c] + t : t;
     }
 }
 
@@ -1104,16 +1115,19 @@ int wgrad_common(const char* fn, const void* x, const void* dz, float* dw, float
     long long rblk = yfs_cdiv(n4, kThreads / G);
     if (rblk > 4096) rblk = 4096;
     const float4* part4 = (const float4*)workspace;
-    if (G == 16) splitk_reduce_kernel<16><<<dim3((unsigned)rblk), dim3(kThreads), 0, s>>>(part4, p.splits, n4, (float4*)dw, accumulate);
-    else if (G == 4) splitk_reduce_kernel<4><<<dim3((unsigned)rblk), dim3(kThreads), 0, s>>>(part4, p.splits, n4, (float4*)dw, accumulate);
-    else splitk_reduce_kernel<1><<<dim3((unsigned)rblk), dim3(kThreads), 0, s>>>(part4, p.splits, n4, (float4*)dw, accumulate);
+    const float* dbp = db ? (const float*)((unsigned char*)workspace + p.partial_bytes) : nullptr;
+    const int cblk = db ? (int)yfs_cdiv(Cout, 16) : 0;
+    const dim3 grid((unsigned)(rblk + cblk));
+    if (G == 16)
+        splitk_reduce_kernel<16><<<grid, dim3(kThreads), 0, s>>>(part4, p.splits, n4, (float4*)dw, accumulate, (int)rblk, dbp,
+                                                                 p.db_splits, Cout, db);
+    else if (G == 4)
+        splitk_reduce_kernel<4><<<grid, dim3(kThreads), 0, s>>>(part4, p.splits, n4, (float4*)dw, accumulate, (int)rblk, dbp,
+                                                                p.db_splits, Cout, db);
+    else
+        splitk_reduce_kernel<1><<<grid, dim3(kThreads), 0, s>>>(part4, p.splits, n4, (float4*)dw, accumulate, (int)rblk, dbp,
+                                                                p.db_splits, Cout, db);
     YFS_CHECK_LAUNCH("splitk_reduce_kernel");
-    if (db) {
-        float* dbp = (float*)((unsigned char*)workspace + p.partial_bytes);
-        colsum_reduce_kernel<<<dim3((unsigned)yfs_cdiv(Cout, 16)), dim3(kThreads), 0, s>>>(dbp, p.db_splits, Cout, db,
-                                                                                            accumulate);
-        YFS_CHECK_LAUNCH("colsum_reduce_kernel");
-    }
     return YFS_OK;
 }
 }  // namespace
