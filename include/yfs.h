@@ -190,6 +190,19 @@ int yfs_conv2d_fwd_pool_bf16(const void *x, const void *w, const float *bias, vo
 int yfs_conv2d_stem_fwd_pool_bf16(const void *xs, const void *w2, const float *bias, void *y_pooled, void *pool_idx,
                                   int64_t N, int Hs, int Ws, int OH, int OW, int Cout, float slope, void *stream);
 
+/* Single-box losses of the reference's practice scripts (pinned by tests/golden/g6_boxloss.npz).
+ * yfs_ciou_loss_f32: ciou_loss  practice/yolo_toy_regressor_3_torch.py:121-138; pred, gt [n,4] xywh -> loss [n] =
+ *   clamp(1 - ciou, 0), optional iou [n], ciou [n] and grad [n,4] = d sum(loss) / d pred (alpha constant, as under the
+ *   reference's torch.no_grad()).
+ * yfs_single_box_loss_fwd_bwd_f32: yolo_single_box_loss  practice/yolo_toy_regressor_torch_20251015.py:368-383; raw [n,4]
+ *   = (x logit, y logit, log w, log h), targets [n,4] xywh -> loss_out[0] (scalar; every smooth-L1 term a mean over the
+ *   n boxes) and grad [n,4] (may be NULL).  n = number of boxes.  Deterministic two-stage reduction. */
+int yfs_ciou_loss_f32(const float *pred, const float *gt, int64_t n, float *loss, float *iou, float *ciou, float *grad,
+                      void *stream);
+size_t yfs_single_box_loss_workspace_bytes(int64_t n);
+int yfs_single_box_loss_fwd_bwd_f32(const float *raw, const float *targets, int64_t n, float *loss_out, float *grad,
+                                    void *workspace, size_t workspace_bytes, void *stream);
+
 /* Epilogue of fc.1  yolo_toy_regressor_torch.py:258-263  Linear(50176, 4096) -> LeakyReLU(0.1) -> Dropout(0.2),
  * fused around a library GEMM.
  * fwd: y[m][n] = drop(leaky(bias[n] + sum_{s<splits} partial[s][m][n])) as bf16; partial fp32 [splits][M][N] (the

@@ -4,7 +4,7 @@ own Python call surface.  Everything here runs hand-written gfx950 HIP kernels f
 from ._lib import YfsError, lib, LIB_PATH  # noqa: F401
 from .boxes import (iou_xywh_torch, iou_xywh_rows, iou_variant, pairwise_iou, decode_head, decode_xywh,  # noqa: F401
                     decode_grid, class_scores, decode_v1, nms, decode_nms, DecodeNms)
-from .loss import YoloV1Loss, MSELoss  # noqa: F401
+from .loss import YoloV1Loss, MSELoss, ciou_loss, yolo_single_box_loss  # noqa: F401
 from .assign import assign_targets_v2, VOC_ANCHORS  # noqa: F401
 from .anchors import estimate_size_priors, kmeans_anchors, anchor_assign  # noqa: F401
 from .metrics import mean_average_precision  # noqa: F401

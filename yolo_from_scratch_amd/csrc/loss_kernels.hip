@@ -162,6 +162,100 @@ __global__ void __launch_bounds__(kThreads) sum_finalize_kernel(const float* __r
     if (threadIdx.x == 0) out[0] = ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) * scale;
 }
 
+// ---- single-box losses of the reference's practice scripts ------------------------------------------------------------
+// ciou_loss  practice/yolo_toy_regressor_3_torch.py:121-138 (+ xywh_to_xyxy :106-110, box_iou_xyxy :112-119): one thread
+// per box pair; forward in the reference's op order, backward by hand in reverse (alpha is a constant: torch.no_grad).
+// torch.maximum / minimum give half of the gradient to each side on exact ties; clamp(min=m) passes it where x >= m.
+__device__ __forceinline__ float tie_ge(float a, float b) { return a > b ? 1.0f : (a == b ? 0.5f : 0.0f); }
+
+__global__ void __launch_bounds__(kThreads) ciou_kernel(const float4* __restrict__ pred, const float4* __restrict__ gt, int64_t n,
+                                                        float* __restrict__ loss, float* __restrict__ iou_out,
+                                                        float* __restrict__ ciou_out, float4* __restrict__ grad) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const float4 pb = pred[i], gb = gt[i];
+    const float p1x = pb.x - pb.z / 2.0f, p1y = pb.y - pb.w / 2.0f, p2x = pb.x + pb.z / 2.0f, p2y = pb.y + pb.w / 2.0f;
+    const float g1x = gb.x - gb.z / 2.0f, g1y = gb.y - gb.w / 2.0f, g2x = gb.x + gb.z / 2.0f, g2y = gb.y + gb.w / 2.0f;
+    const float tlx = fmaxf(p1x, g1x), tly = fmaxf(p1y, g1y), brx = fminf(p2x, g2x), bry = fminf(p2y, g2y);
+    const float dwx = brx - tlx, dwy = bry - tly;
+    const float iw = dwx > 0.0f ? dwx : 0.0f, ih = dwy > 0.0f ? dwy : 0.0f;
+    const float inter = iw * ih;
+    const float pwr = p2x - p1x, phr = p2y - p1y, gwr = g2x - g1x, ghr = g2y - g1y;
+    const float wa = pwr > 0.0f ? pwr : 0.0f, ha = phr > 0.0f ? phr : 0.0f;
+    const float wb = gwr > 0.0f ? gwr : 0.0f, hb = ghr > 0.0f ? ghr : 0.0f;
+    const float uni = wa * ha + wb * hb - inter + 1e-9f;
+    const float iou = inter / uni;
+    const float pcx = (p1x + p2x) / 2.0f, pcy = (p1y + p2y) / 2.0f, gcx = (g1x + g2x) / 2.0f, gcy = (g1y + g2y) / 2.0f;
+    const float ddx = pcx - gcx, ddy = pcy - gcy;
+    const float cd = ddx * ddx + ddy * ddy;
+    const float etlx = fminf(p1x, g1x), etly = fminf(p1y, g1y), ebrx = fmaxf(p2x, g2x), ebry = fmaxf(p2y, g2y);
+    const float ex = ebrx - etlx, ey = ebry - etly;
+    const float c2 = ex * ex + ey * ey + 1e-9f;
+    const float pw = pwr > 1e-9f ? pwr : 1e-9f, ph = phr > 1e-9f ? phr : 1e-9f;
+    const float gw = gwr > 1e-9f ? gwr : 1e-9f, gh = ghr > 1e-9f ? ghr : 1e-9f;
+    const float kv = 4.0f / (3.14159265358979323846f * 3.14159265358979323846f);
+    const float r = pw / ph;
+    const float A = atanf(gw / gh) - atanf(r);
+    const float v = kv * (A * A);
+    const float alpha = v / (1.0f - iou + v + 1e-9f);
+    const float ciou = iou - cd / c2 - alpha * v;
+    const float one_m = 1.0f - ciou;
+    loss[i] = one_m > 0.0f ? one_m : 0.0f;
+    if (iou_out) iou_out[i] = iou;
+    if (ciou_out) ciou_out[i] = ciou;
+    if (!grad) return;
+    // ---- backward of sum(loss) ----
+    const float dciou = one_m >= 0.0f ? -1.0f : 0.0f;
+    float d1x = 0.f, d1y = 0.f, d2x = 0.f, d2y = 0.f;                 // gradients of the pred corners
+    // v = kv * A^2, A = const - atan(pw / ph)
+    const float dA = -dciou * alpha * kv * 2.0f * A;
+    const float dr = -dA / (1.0f + r * r);
+    const float dpw = (pwr >= 1e-9f) ? dr / ph : 0.0f;
+    const float dph = (phr >= 1e-9f) ? -dr * pw / (ph * ph) : 0.0f;
+    d2x += dpw; d1x -= dpw; d2y += dph; d1y -= dph;
+    // - cd / c2
+    const float dcd = -dciou / c2, dc2 = dciou * cd / (c2 * c2);
+    const float dex = 2.0f * ex * dc2, dey = 2.0f * ey * dc2;
+    d2x += dex * tie_ge(p2x, g2x); d1x -= dex * tie_ge(g1x, p1x);     // ebr = max(p2, g2), etl = min(p1, g1)
+    d2y += dey * tie_ge(p2y, g2y); d1y -= dey * tie_ge(g1y, p1y);
+    const float dpcx = 2.0f * ddx * dcd, dpcy = 2.0f * ddy * dcd;
+    d1x += 0.5f * dpcx; d2x += 0.5f * dpcx; d1y += 0.5f * dpcy; d2y += 0.5f * dpcy;
+    // iou = inter / uni
+    const float duni = -dciou * inter / (uni * uni);
+    const float dinter = dciou / uni - duni;
+    const float dwa = duni * ha * (pwr >= 0.0f ? 1.0f : 0.0f), dha = duni * wa * (phr >= 0.0f ? 1.0f : 0.0f);
+    d2x += dwa; d1x -= dwa; d2y += dha; d1y -= dha;
+    const float diw = dinter * ih * (dwx >= 0.0f ? 1.0f : 0.0f), dih = dinter * iw * (dwy >= 0.0f ? 1.0f : 0.0f);
+    d2x += diw * tie_ge(g2x, p2x); d1x -= diw * tie_ge(p1x, g1x);     // br = min(p2, g2), tl = max(p1, g1)
+    d2y += dih * tie_ge(g2y, p2y); d1y -= dih * tie_ge(p1y, g1y);
+    grad[i] = make_float4(d1x + d2x, d1y + d2y, 0.5f * (d2x - d1x), 0.5f * (d2y - d1y));
+}
+
+// yolo_single_box_loss  practice/yolo_toy_regressor_torch_20251015.py:368-383: 2 (sl1(sig(x), tx) + sl1(sig(y), ty)) +
+// 4 (sl1(w_log, log(tw + eps)) + sl1(h_log, log(th + eps))), each smooth_l1 (beta = 1) a MEAN over the n boxes.
+__device__ __forceinline__ float sl1(float d) { const float a = fabsf(d); return a < 1.0f ? 0.5f * d * d : a - 0.5f; }
+__device__ __forceinline__ float sl1_grad(float d) { return fabsf(d) < 1.0f ? d : (d > 0.0f ? 1.0f : -1.0f); }
+
+__global__ void __launch_bounds__(kThreads) single_box_loss_kernel(const float4* __restrict__ raw, const float4* __restrict__ tg,
+                                                                   int64_t n, float inv_n, float4* __restrict__ grad,
+                                                                   float* __restrict__ partial) {
+    __shared__ float wsum[kThreads / 64];
+    float acc = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+        const float4 rw = raw[i], t = tg[i];
+        const float x = yfs_sigmoid(rw.x), y = yfs_sigmoid(rw.y);
+        const float dx = x - t.x, dy = y - t.y, dw = rw.z - logf(t.z + 1e-6f), dh = rw.w - logf(t.w + 1e-6f);
+        acc += 2.0f * (sl1(dx) + sl1(dy)) + 4.0f * (sl1(dw) + sl1(dh));
+        if (grad)
+            grad[i] = make_float4(2.0f * sl1_grad(dx) * x * (1.0f - x) * inv_n, 2.0f * sl1_grad(dy) * y * (1.0f - y) * inv_n,
+                                  4.0f * sl1_grad(dw) * inv_n, 4.0f * sl1_grad(dh) * inv_n);
+    }
+    acc = yfs_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
 int64_t mse_blocks(int64_t n) {
     int64_t b = yfs_cdiv(n, kThreads);
     return b < 2048 ? b : 2048;
@@ -212,6 +306,32 @@ YFS_API int yfs_mse_fwd_bwd_f32(const float* pred, const float* target, int64_t 
     const int64_t nblk = mse_blocks(n);
     mse_kernel<<<dim3((unsigned)nblk), dim3(kThreads), 0, s>>>(pred, target, n, 1.0f / (float)n, grad, (float*)workspace);
     YFS_CHECK_LAUNCH("mse_kernel");
+    sum_finalize_kernel<<<1, kThreads, 0, s>>>((const float*)workspace, nblk, 1.0f / (float)n, loss_out);
+    YFS_CHECK_LAUNCH("sum_finalize_kernel");
+    return YFS_OK;
+}
+
+YFS_API int yfs_ciou_loss_f32(const float* pred, const float* gt, int64_t n, float* loss, float* iou, float* ciou, float* grad,
+                              void* stream) {
+    YFS_REQUIRE(pred && gt && loss && n > 0, YFS_ERR_INVALID_ARG, "yfs_ciou_loss_f32: null pointer or n <= 0");
+    ciou_kernel<<<dim3((unsigned)yfs_cdiv(n, kThreads)), dim3(kThreads), 0, (hipStream_t)stream>>>(
+        (const float4*)pred, (const float4*)gt, n, loss, iou, ciou, (float4*)grad);
+    YFS_CHECK_LAUNCH("ciou_kernel");
+    return YFS_OK;
+}
+
+YFS_API size_t yfs_single_box_loss_workspace_bytes(int64_t n) { return yfs_mse_workspace_bytes(n); }
+
+YFS_API int yfs_single_box_loss_fwd_bwd_f32(const float* raw, const float* targets, int64_t n, float* loss_out, float* grad,
+                                            void* workspace, size_t workspace_bytes, void* stream) {
+    YFS_REQUIRE(raw && targets && loss_out && n > 0, YFS_ERR_INVALID_ARG, "yfs_single_box_loss_fwd_bwd_f32: null pointer or n <= 0");
+    YFS_REQUIRE(workspace && workspace_bytes >= yfs_single_box_loss_workspace_bytes(n), YFS_ERR_WORKSPACE,
+                "yfs_single_box_loss_fwd_bwd_f32: workspace needs %zu bytes", yfs_single_box_loss_workspace_bytes(n));
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t nblk = mse_blocks(n);
+    single_box_loss_kernel<<<dim3((unsigned)nblk), dim3(kThreads), 0, s>>>((const float4*)raw, (const float4*)targets, n,
+                                                                          1.0f / (float)n, (float4*)grad, (float*)workspace);
+    YFS_CHECK_LAUNCH("single_box_loss_kernel");
     sum_finalize_kernel<<<1, kThreads, 0, s>>>((const float*)workspace, nblk, 1.0f / (float)n, loss_out);
     YFS_CHECK_LAUNCH("sum_finalize_kernel");
     return YFS_OK;

@@ -97,3 +97,69 @@ class MSELoss(torch.nn.Module):
 
     def forward(self, pred, target):
         return _MseFn.apply(pred, target)
+
+
+# ---- single-box losses of the reference's practice scripts ---------------------------------------------------------
+class _CiouFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, gt):
+        L.require_cuda(pred, gt)
+        if pred.shape != gt.shape or pred.shape[-1] != 4:
+            raise L.YfsError(f"ciou_loss: expected two [..., 4] tensors, got {tuple(pred.shape)} and {tuple(gt.shape)}")
+        p = pred.detach().to(torch.float32).contiguous()
+        g = gt.detach().to(torch.float32).contiguous()
+        n = p.numel() // 4
+        lead = pred.shape[:-1]
+        loss = torch.empty(lead, device=p.device, dtype=torch.float32)
+        iou, ciou = torch.empty_like(loss), torch.empty_like(loss)
+        grad = torch.empty_like(p) if ctx.needs_input_grad[0] else None
+        L.check(L.lib().yfs_ciou_loss_f32(L.ptr(p), L.ptr(g), L.i64(n), L.ptr(loss), L.ptr(iou), L.ptr(ciou), L.ptr(grad),
+                                          L.stream()), "yfs_ciou_loss_f32")
+        ctx.grad, ctx.in_dtype = grad, pred.dtype
+        ctx.mark_non_differentiable(iou, ciou)
+        return loss, iou, ciou
+
+    @staticmethod
+    def backward(ctx, g_loss, g_iou, g_ciou):
+        if ctx.grad is None:
+            return None, None
+        return (ctx.grad * g_loss.unsqueeze(-1)).to(ctx.in_dtype), None
+
+
+def ciou_loss(pred_xywh, gt_xywh):
+    """practice/yolo_toy_regressor_3_torch.py:121-138: -> (clamp(1 - ciou, 0), iou, ciou), each [...].  The loss is
+    differentiable with respect to ``pred_xywh`` (alpha constant, as under the reference's no_grad); iou and ciou are
+    returned for logging only."""
+    return _CiouFn.apply(pred_xywh, gt_xywh)
+
+
+class _SingleBoxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raw, targets):
+        L.require_cuda(raw, targets)
+        if raw.shape != targets.shape or raw.shape[-1] != 4:
+            raise L.YfsError(f"yolo_single_box_loss: expected two [..., 4] tensors, got {tuple(raw.shape)} and "
+                             f"{tuple(targets.shape)}")
+        r = raw.detach().to(torch.float32).contiguous()
+        t = targets.detach().to(torch.float32).contiguous()
+        n = r.numel() // 4
+        ws_bytes = L.lib().yfs_single_box_loss_workspace_bytes(L.i64(n))
+        ws = torch.empty(max(ws_bytes // 4, 1), device=r.device, dtype=torch.float32)
+        out = torch.empty(1, device=r.device, dtype=torch.float32)
+        grad = torch.empty_like(r) if ctx.needs_input_grad[0] else None
+        L.check(L.lib().yfs_single_box_loss_fwd_bwd_f32(L.ptr(r), L.ptr(t), L.i64(n), L.ptr(out), L.ptr(grad), L.ptr(ws),
+                                                        L.c_size(ws_bytes), L.stream()), "yfs_single_box_loss_fwd_bwd_f32")
+        ctx.grad, ctx.in_dtype = grad, raw.dtype
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.grad is None:
+            return None, None
+        return (ctx.grad * g).to(ctx.in_dtype), None
+
+
+def yolo_single_box_loss(raw, targets):
+    """practice/yolo_toy_regressor_torch_20251015.py:368-383: raw [...,4] = (x logit, y logit, log w, log h), targets
+    [...,4] xywh -> scalar 2 (sl1(x) + sl1(y)) + 4 (sl1(w) + sl1(h)), smooth-L1 means over the boxes."""
+    return _SingleBoxFn.apply(raw, targets)
