@@ -33,3 +33,23 @@ def test_is_better_ordering():
     assert run.is_better({"val_iou": 0.5, "val": 0.9, "epoch": 1}, a)            # then lower val loss
     assert run.is_better({"val_iou": 0.5, "val": 1.0, "epoch": 4}, a)            # then later epoch
     assert not run.is_better(dict(a), a)                                         # strictly better only
+
+
+def test_init_head_biases_prior_logits():
+    """practice/yolo_toy_regressor_3_torch.py:263-276 on a plain torch head (host code, no kernels)."""
+    import math
+    import torch.nn as nn
+    from yolo_from_scratch_amd.anchors import init_head_biases
+
+    class M(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc = nn.Sequential(nn.Flatten(), nn.Linear(16, 8), nn.ReLU(), nn.Linear(8, 4))
+    m = M()
+    torch.manual_seed(0)
+    last = init_head_biases(m, prior_xy=(0.5, 0.4), prior_wh=(0.25, 0.35))
+    assert last is m.fc[3]
+    exp = [math.log(p / (1 - p)) for p in (0.5, 0.4, 0.25, 0.35)]
+    assert torch.allclose(m.fc[3].bias.detach(), torch.tensor(exp, dtype=torch.float32))
+    bound = math.sqrt(6.0 / (8 + 4))
+    assert float(m.fc[3].weight.abs().max()) <= bound

@@ -19,6 +19,28 @@ def estimate_size_priors(loader):
     return (min(max(w, eps), 1 - eps), min(max(h, eps), 1 - eps))
 
 
+def init_head_biases(model, head_attr="fc", prior_xy=(0.5, 0.5), prior_wh=(0.25, 0.35)):
+    """practice/yolo_toy_regressor_3_torch.py:263-276: Xavier-uniform weights and prior logits in the first four
+    biases of the head's last Linear layer.  In-place writes: a FlatSGD created earlier notices them through the
+    tensor versions (train.bf16_shadow)."""
+    import math
+    import torch.nn as nn
+    head = getattr(model, head_attr)
+    last = None
+    for m in reversed(list(head.modules())):
+        if isinstance(m, nn.Linear):
+            last = m
+            break
+    if last is None:
+        raise L.YfsError("init_head_biases: no Linear layer in the head")
+    nn.init.xavier_uniform_(last.weight)
+    with torch.no_grad():
+        last.bias.zero_()
+        for i, p in enumerate((prior_xy[0], prior_xy[1], prior_wh[0], prior_wh[1])):
+            last.bias[i] = math.log(p / (1 - p))
+    return last
+
+
 @torch.no_grad()
 def anchor_assign(wh, anchors):
     """wh [n,2], anchors [k,2] (CUDA) -> (assign int32 [n], best_iou fp32 [n]); argmax shape IoU, ties -> lowest."""
