@@ -38,6 +38,7 @@ def test_is_better_ordering():
 def test_init_head_biases_prior_logits():
     """practice/yolo_toy_regressor_3_torch.py:263-276 on a plain torch head (host code, no kernels)."""
     import math
+    import torch
     import torch.nn as nn
     from yolo_from_scratch_amd.anchors import init_head_biases
 
