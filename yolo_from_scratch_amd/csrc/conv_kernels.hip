@@ -1015,6 +1015,9 @@ WgradPlan plan_wgrad(int64_t M, int Cin, int Cout, int taps, bool wide192 = fals
     WgradPlan p;
     p.bx = (Cin % 128 == 0) ? 128 : ((Cin % 192 == 0 && Cout % 128 == 0) ? 192 : 64);
     p.bz = (Cout % 128 == 0) ? 128 : ((Cout % 192 == 0 && (p.bx == 64 || wide192)) ? 192 : 64);
+    static const int force_tile = [] { const char* e = getenv("YFS_WGRAD_TILE"); return e ? atoi(e) : 0; }();   // sweeps
+    if (force_tile == 64 && !wide192) p.bx = p.bz = 64;
+    if (force_tile == 12864 && !wide192 && p.bx == 128 && p.bz == 128) p.bz = 64;
     p.citiles = Cin / p.bx;
     p.cotiles = Cout / p.bz;
     p.ktiles = (int)yfs_cdiv(M, 64);
