@@ -334,3 +334,33 @@ def test_deferred_linear_gradient_under_data_parallel_exchange(monkeypatch):
     for pa, pb in zip(na.parameters(), nb.parameters()):
         assert _rel(pa, pb) < 2e-5
     assert _rel(oa.flat_m, ob.flat_m) < 2e-5
+
+
+def test_config2_full_size_batch_properties():
+    """BASELINE configs[1] at full size (448x448, batch 64): properties that need no CPU oracle.  (1) Every output pixel's
+    reduction is independent of the batch it sits in, so the backbone's forward over 64 images is bit-identical to four
+    forwards over 16.  (2) Weight gradients are sums over pixels: the gradient of the whole batch equals the sum of the
+    four sub-batch gradients up to fp32 summation order (the split-K partition changes with the batch)."""
+    torch.manual_seed(0)
+    feat = ym.YoloRegressorModel(head_out=1470).feat.to(DEV)
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(64, 3, 448, 448, generator=g).to(DEV)
+    dy = (torch.randn(64, 1024, 7, 7, generator=g) * 1e-2).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+    def run(xb, dyb):
+        for p in feat.parameters():
+            p.grad = None
+        y = feat(xb)
+        y.backward(dyb)
+        return y.detach(), [p.grad.detach().float().clone() for p in feat.parameters()]
+    y_full, g_full = run(x, dy)
+    assert y_full.shape == (64, 1024, 7, 7)
+    g_sum = None
+    for i in range(0, 64, 16):
+        y_part, g_part = run(x[i:i + 16], dy[i:i + 16])
+        assert torch.equal(y_part, y_full[i:i + 16])
+        g_sum = g_part if g_sum is None else [a + b for a, b in zip(g_sum, g_part)]
+    # the activation gradients are rounded to bf16 per layer identically in both runs (same per-pixel arithmetic),
+    # so only the fp32 accumulation order over pixels differs
+    for a, b in zip(g_full, g_sum):
+        assert _rel(a, b) < 1e-4
