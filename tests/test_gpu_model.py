@@ -364,3 +364,12 @@ def test_config2_full_size_batch_properties():
     # so only the fp32 accumulation order over pixels differs
     for a, b in zip(g_full, g_sum):
         assert _rel(a, b) < 1e-4
+
+
+def test_wrong_resolution_raises_the_references_shape_error():
+    """the reference's full forward at 224x224 fails in fc.1 with torch's matmul shape error; the
+    drop-in fails the same way (same exception type and wording) instead of reading out of bounds."""
+    torch.manual_seed(0)
+    model = ym.YoloRegressorModel(head_out=4, image_size=64).to(DEV)          # fc.1 sized for 64x64 inputs (1024 features)
+    with pytest.raises(RuntimeError, match=r"mat1 and mat2 shapes cannot be multiplied \(2x4096 and 1024x4096\)"):
+        model(torch.rand(2, 3, 128, 128, device=DEV))

@@ -398,6 +398,11 @@ class _LinearFn(torch.autograd.Function):
         # check although this view's bytes are untouched
         ctx.w16 = w16
         ctx.wb, ctx.in_dtype = (weight, bias), x.dtype
+        if x16.dim() != 2 or x16.shape[1] != w16.shape[1]:
+            # the reference's own failure mode (a 224x224 input reaches fc.1 with 16384 features),
+            # with torch's wording so callers that match on it keep working
+            raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({x16.shape[0]}x{x16.shape[-1]} and "
+                               f"{w16.shape[1]}x{w16.shape[0]})")
         m, k = x16.shape
         n = w16.shape[0]
         ctx.fused = slope is not None
