@@ -410,7 +410,9 @@ int launch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
 // 256x128 / 4 waves / 32-deep (810-980), issuing the loads between the MFMAs instead of in a burst (-6 %),
 // 256x256 / 4 waves of 128x128 at one wave per SIMD with all 256 AGPRs as accumulators (the vendor GEMM's shape;
 // compiles without spills but the compiler's schedule leaves the single wave exposed: 730-890), 256x192 / 8 waves for
-// the 192-channel outputs (stem + pool 584 vs 571 us, feat.2 dgrad 759 vs 738 us: no gain).
+// the 192-channel outputs (stem + pool 584 vs 571 us, feat.2 dgrad 759 vs 738 us: no gain), a 3-deep ring for grids of
+// at most one workgroup per CU (feat.25-27, 200 tiles: 101 vs 96 us — a lone workgroup is not latency-bound either: its
+// 32 KiB per K-step at ~31 B/clk is 1060 of the 1390 cycles a step takes, the same per-CU staging limit as with two).
 // 128x192 serves the 192-channel outputs (pixel tile read once instead of three times with 128x64).  YFS_IGEMM_TILE=128|256|2562 forces a variant for benchmarking.
 template <int EPI, bool SUB>
 int dispatch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
