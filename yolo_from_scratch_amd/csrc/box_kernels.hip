@@ -321,6 +321,7 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
     unsigned char* tail = smem + 20 * (size_t)cap + 8 * (size_t)npow;
     int* kflag = reinterpret_cast<int*>(tail);                                                 // 4*cap
     int* segs = kflag + cap;                                                                   // 4*cap
+    unsigned long long* over = reinterpret_cast<unsigned long long*>(tail + 8 * (size_t)cap);  // 8*cap  overlap masks
     float* rawlds = reinterpret_cast<float*>(tail);   // fused: raw-head staging, dead before kflag / segs are used
 
     // ---- A: decode / filter, candidates compacted in box-index order (ballot prefix, no atomics) ----
@@ -406,61 +407,108 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
     int ns = 2;
     while (ns < K) ns <<= 1;                       // K <= cap <= npow
     for (int p = K + tid; p < ns; p += kThreads) key[p] = ~0ull;
-    for (int p = tid; p < K; p += kThreads) kflag[p] = 0;
-    if (tid == 0) ctl[2] = 0;
     __syncthreads();
     bitonic_sort(key, ns, tid);
-    for (int p = tid; p < K; p += kThreads)
-        if (p == 0 || (key[p] >> kClsShift) != (key[p - 1] >> kClsShift)) segs[atomicAdd(&ctl[2], 1)] = p;   // any order
+    // segment starts in ascending order (ordered ballot compaction, as in phase A) -> lengths by subtraction
+    int nseg = 0;
+    for (int p0 = 0; p0 < K; p0 += kThreads) {
+        const int p = p0 + tid;
+        const bool st = p < K && (p == 0 || (key[p] >> kClsShift) != (key[p - 1] >> kClsShift));
+        const unsigned long long bal = __ballot(st);
+        if (lane == 0) wcnt[par][wave] = __builtin_popcountll(bal);
+        __syncthreads();
+        int off = nseg, tot = 0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) {
+            const int cw = wcnt[par][w];
+            off += w < wave ? cw : 0;
+            tot += cw;
+        }
+        if (st) segs[off + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = p;
+        nseg += tot;
+        par ^= 1;
+    }
     __syncthreads();
-    const int nseg = ctl[2];
 
     // ---- C: greedy suppression per class segment ----
-    // The loop over kept boxes is serial per segment and every iteration costs the same ~45 VALU whether 5 or 64 lanes
-    // hold a member; config 4 has ~23 members per class.  A wave therefore takes TWO segments at a time, one per
-    // 32-lane half (each half reads "its" kept box out of lane i / lane 32 + i of the same registers); a pair in which
-    // either segment is longer than 32 falls back to one segment per wave.
-    auto seg_len = [&](int p0) {
-        const unsigned long long c = key[p0] >> kClsShift;
-        int len = 0;   // leading run of class c from p0
-        for (int base = p0; base < K; base += 64) {
-            const int p = base + lane;
-            const bool same = p < K && (key[p] >> kClsShift) == c;
-            const unsigned long long bal = __ballot(same);
-            if (bal == ~0ull) { len += 64; continue; }
-            len += __builtin_ctzll(~bal);
-            break;
-        }
-        return len;
-    };
-    auto one_segment = [&](int p0, int len) {
-        if (len <= 64) {
-            // member `lane` lives in this lane's registers; `removed` is wave-uniform
-            const bool mine = lane < len;
-            const int sj = mine ? (int)(key[p0 + lane] & kSlotMask) : 0;
-            const float4 q = cbox[sj];
-            unsigned long long removed = 0;
-            for (int i = 0; i < len; ++i) {
-                if ((removed >> i) & 1ull) continue;
-                // i is wave-uniform: the kept box comes out of lane i's registers (v_readlane), not out of LDS
-                float4 pb;
-                pb.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.x), i));
-                pb.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.y), i));
-                pb.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.z), i));
-                pb.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.w), i));
-                const float v = yfs_iou_corners(pb.x, pb.y, pb.z, pb.w, q.x, q.y, q.z, q.w);
-                removed |= __ballot(mine && lane > i && v > g.iou_thr);
+    // The textbook loop (for every kept box, test all later boxes) is one serial chain per segment and costs the same
+    // ~45 VALU per step whether 5 or 64 lanes hold a member: with ~23 members per class most lanes idle.  Instead:
+    //   C1  every (earlier i, later j) pair of every segment of <= 64 members is one work item, spread over all 256
+    //       threads: segment by binary search over the prefix sums of pair counts, (i, j) from the triangular index;
+    //       an overlap above the threshold sets bit i of over[j] (LDS atomic OR);
+    //   C2  one thread per segment walks its members in score order: j survives iff no surviving earlier member
+    //       overlaps it, (over[j] & kept) == 0 — exactly the greedy rule, now a chain of one AND per member.
+    // Segments longer than 64 keep the wave-per-segment loop.
+    int* ppre = kflag;   // [nseg] exclusive prefix sums of pair counts; the region becomes the keep flags after C1
+    auto seg_start = [&](int sgi) { return segs[sgi]; };
+    auto seg_length = [&](int sgi) { return (sgi + 1 < nseg ? segs[sgi + 1] : K) - segs[sgi]; };
+    if (wave == 0) {     // exclusive scan of the pair counts, 64 segments per round
+        int carry = 0;
+        for (int s0 = 0; s0 < nseg; s0 += 64) {
+            const int sgi = s0 + lane;
+            int cnt = 0;
+            if (sgi < nseg) {
+                const int len = seg_length(sgi);
+                cnt = len <= 64 ? len * (len - 1) / 2 : 0;
             }
-            if (mine && !((removed >> lane) & 1ull)) kflag[sj] = 1;
-        } else {
-            // member lane + 64 t <-> bit t of this lane's `rem`
+            int incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int v = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += v;
+            }
+            if (sgi < nseg) ppre[sgi] = carry + incl - cnt;
+            carry += __shfl(incl, 63, 64);
+        }
+        if (lane == 0) ctl[3] = carry;   // total number of pairs
+    }
+    for (int p = tid; p < K; p += kThreads) over[p] = 0ull;
+    __syncthreads();
+    const int P = ctl[3];
+    for (int q = tid; q < P; q += kThreads) {
+        int lo = 0, hi = nseg;                       // last segment with ppre <= q (empty ones share their successor's value)
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (ppre[mid] <= q) lo = mid; else hi = mid;
+        }
+        const int r = q - ppre[lo];
+        int j = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)r)) * 0.5f);
+        while (j * (j - 1) / 2 > r) --j;
+        while ((j + 1) * j / 2 <= r) ++j;
+        const int i = r - j * (j - 1) / 2;             // 0 <= i < j < len
+        const int p0 = seg_start(lo);
+        const float4 a = cbox[key[p0 + i] & kSlotMask], bq = cbox[key[p0 + j] & kSlotMask];
+        const float v = yfs_iou_corners(a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w);
+        if (v > g.iou_thr) atomicOr(&over[p0 + j], 1ull << i);
+    }
+    __syncthreads();
+    for (int p = tid; p < K; p += kThreads) kflag[p] = 0;     // (was ppre)
+    __syncthreads();
+    for (int sgi = tid; sgi < nseg; sgi += kThreads) {
+        const int p0 = seg_start(sgi), len = seg_length(sgi);
+        if (len > 64) continue;
+        unsigned long long kept = 0;
+        for (int j = 0; j < len; ++j) {
+            if ((over[p0 + j] & kept) == 0ull) {
+                kept |= 1ull << j;
+                kflag[key[p0 + j] & kSlotMask] = 1;
+            }
+        }
+    }
+    {   // long segments: one wave each; member lane + 64 t <-> bit t of this lane's `rem`
+        int nlong = 0;
+        for (int sgi = 0; sgi < nseg; ++sgi) {
+            const int len = seg_length(sgi);
+            if (len <= 64) continue;
+            if ((nlong++ & (kThreads / 64 - 1)) != wave) continue;
+            const int p0 = seg_start(sgi);
             const int T = (len + 63) >> 6;
             unsigned long long rem = 0;
             for (int i = 0; i < len; ++i) {
                 const int ti = i >> 6, own = i & 63;
-                const unsigned lo = (unsigned)__shfl((int)(unsigned)(rem & 0xffffffffull), own, 64);
-                const unsigned hi = (unsigned)__shfl((int)(unsigned)(rem >> 32), own, 64);
-                const unsigned long long w = ((unsigned long long)hi << 32) | lo;
+                const unsigned lo32 = (unsigned)__shfl((int)(unsigned)(rem & 0xffffffffull), own, 64);
+                const unsigned hi32 = (unsigned)__shfl((int)(unsigned)(rem >> 32), own, 64);
+                const unsigned long long w = ((unsigned long long)hi32 << 32) | lo32;
                 if ((w >> ti) & 1ull) continue;
                 const int si = (int)(key[p0 + i] & kSlotMask);
                 if (lane == 0) kflag[si] = 1;
@@ -475,47 +523,6 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
                 }
             }
         }
-    };
-    for (int sg = 2 * wave; sg < nseg; sg += 2 * (kThreads / 64)) {
-        const int pA = segs[sg];
-        const int lenA = seg_len(pA);
-        if (sg + 1 >= nseg) { one_segment(pA, lenA); break; }
-        const int pB = segs[sg + 1];
-        const int lenB = seg_len(pB);
-        if (lenA > 32 || lenB > 32) {
-            one_segment(pA, lenA);
-            one_segment(pB, lenB);
-            continue;
-        }
-        const int hl = lane & 31;
-        const bool upper = lane >= 32;
-        const int mylen = upper ? lenB : lenA;
-        const bool mine = hl < mylen;
-        const int sj = mine ? (int)(key[(upper ? pB : pA) + hl] & kSlotMask) : 0;
-        const float4 q = cbox[sj];
-        unsigned remA = 0, remB = 0;            // wave-uniform
-        const int lmax = lenA > lenB ? lenA : lenB;
-        for (int i = 0; i < lmax; ++i) {
-            const bool actA = i < lenA && !((remA >> i) & 1u), actB = i < lenB && !((remB >> i) & 1u);
-            if (!actA && !actB) continue;
-            float4 pa, pb;
-            pa.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.x), i));
-            pa.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.y), i));
-            pa.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.z), i));
-            pa.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.w), i));
-            pb.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.x), 32 + i));
-            pb.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.y), 32 + i));
-            pb.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.z), 32 + i));
-            pb.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.w), 32 + i));
-            const float4 p = upper ? pb : pa;
-            const float v = yfs_iou_corners(p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w);
-            const bool act = upper ? actB : actA;
-            const unsigned long long bal = __ballot(act && mine && hl > i && v > g.iou_thr);
-            remA |= (unsigned)bal;
-            remB |= (unsigned)(bal >> 32);
-        }
-        const unsigned myrem = upper ? remB : remA;
-        if (mine && !((myrem >> hl) & 1u)) kflag[sj] = 1;
     }
     if (tid == 0) ctl[1] = 0;
     __syncthreads();
@@ -543,7 +550,7 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
 
 size_t nms_lds_bytes(int cap, int npow, bool fused, int bpc, int D) {
     size_t head = 20 * (size_t)cap + 8 * (size_t)npow;
-    size_t tail = 8 * (size_t)cap;
+    size_t tail = 16 * (size_t)cap;   // keep flags / pair prefix, segment starts, overlap masks
     if (fused) {
         size_t rawb = (size_t)YFS_STAGE_FLOATS(bpc * D) * 4;
         if (rawb > tail) tail = rawb;
