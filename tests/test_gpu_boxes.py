@@ -103,6 +103,10 @@ def _nms_case(N, A, seed, ncls=20, pass_frac=0.15, tie=False, clustered=False):
     (3, 845, {"tie": True, "ncls": 2}), (3, 845, {"clustered": True, "ncls": 1, "pass_frac": 0.6}),
     (2, 1, {}), (2, 63, {"pass_frac": 1.0}), (2, 64, {"pass_frac": 1.0}), (2, 65, {"pass_frac": 1.0, "clustered": True}),
     (1, 2048, {"pass_frac": 0.9, "clustered": True, "ncls": 3}), (64, 845, {"clustered": True}),
+    # class ids >= 64: the keys carry the class and a second sort restores the output order (two-sort path)
+    (3, 845, {"ncls": 200}), (2, 300, {"ncls": 70, "clustered": True, "pass_frac": 0.8}),
+    # exactly 64 classes (largest id 63): still the one-sort path; one class only
+    (2, 845, {"ncls": 64, "clustered": True}), (2, 500, {"ncls": 1, "pass_frac": 0.1}),
 ])
 def test_nms_kept_indices_bit_exact(N, A, kw):
     boxes, score, cls = _nms_case(N, A, seed=N * 7 + A, **kw)

@@ -311,6 +311,7 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int wcnt[2][kThreads / 64];
     __shared__ int ctl[4];
+    __shared__ int cstart_s[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t n = blockIdx.x;
     const int A = g.A, cap = g.cap, npow = g.npow;
@@ -327,6 +328,8 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
     // ---- A: decode / filter, candidates compacted in box-index order (ballot prefix, no atomics) ----
     int K = 0;
     int par = 0;
+    int maxcls = 0;            // largest class id among this thread's candidates
+    if (tid == 0) ctl[0] = 0;
     auto compact = [&](bool pass, int bi, float4 corners, float score, int cls) {
         const unsigned long long bal = __ballot(pass);
         if (lane == 0) wcnt[par][wave] = __builtin_popcountll(bal);
@@ -341,8 +344,9 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
         if (pass) {
             const int slot = off + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
             cbox[slot] = corners;
-            cidx[slot] = bi;
+            cidx[slot] = bi | (int)(((unsigned)cls & 0x1FFFFFu) << kSlotBits);   // [class:21 | box index:11]
             key[slot] = make_key(cls, score, slot);
+            maxcls = ((unsigned)cls & 0x1FFFFFu) > (unsigned)maxcls ? (int)((unsigned)cls & 0x1FFFFFu) : maxcls;
         }
         K += tot;
         par ^= 1;
@@ -404,13 +408,89 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
     // ---- B: sort by (class, score desc, index): every class becomes one contiguous, score-ordered segment ----
     // Class-wise NMS never compares boxes of different classes, so suppression runs per segment: with ~450
     // candidates in 20 classes that is ~5 K IoU evaluations per image instead of the ~100 K of an all-pairs mask.
+    // Two orders are needed: class-major for the suppression, global (score, index) for the output.  When every class id
+    // is below 64 (any YOLO head) ONE bitonic sort by (score, index) serves both: a stable counting sort by class on top
+    // of it (ballot ranks per 64-position chunk, 64 x chunks table of counts) yields the class segments in score order,
+    // and the output is an ordered compaction of the kept flags along the sorted array.  Otherwise the keys carry the
+    // class in their top bits and a second sort restores the output order (phase D).
+    {
+        int mc = maxcls;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const int o = __shfl_xor(mc, d, 64);
+            mc = o > mc ? o : mc;
+        }
+        if (lane == 0) atomicMax(&ctl[0], mc);
+    }
     int ns = 2;
     while (ns < K) ns <<= 1;                       // K <= cap <= npow
+    __syncthreads();
+    const bool onesort = ctl[0] < 64 && cap >= 128;   // (cslot sits behind 64 segment starts inside the 4*cap segs region)
     for (int p = K + tid; p < ns; p += kThreads) key[p] = ~0ull;
+    if (onesort)
+        for (int p = tid; p < K; p += kThreads) key[p] &= (1ull << kClsShift) - 1ull;
     __syncthreads();
     bitonic_sort(key, ns, tid);
-    // segment starts in ascending order (ordered ballot compaction, as in phase A) -> lengths by subtraction
     int nseg = 0;
+    unsigned short* cslot = reinterpret_cast<unsigned short*>(segs + 64);   // onesort: slot of the q-th box, class-major
+    if (onesort) {
+        unsigned short* cnt = reinterpret_cast<unsigned short*>(over);      // [chunks][64]; `over` is free until C1
+        const int nchunks = (K + 63) >> 6;
+        for (int e = tid; e < nchunks * 64; e += kThreads) cnt[e] = 0;
+        __syncthreads();
+        constexpr int kMaxR = (YFS_NMS_MAX_BOXES + kThreads - 1) / kThreads;
+        int rankw[kMaxR], clsr[kMaxR], slotr[kMaxR];
+#pragma unroll
+        for (int r = 0; r < kMaxR; ++r) {
+            const int p = tid + r * kThreads;              // chunk = wave + 4 r, lane = position inside the chunk
+            rankw[r] = 0; clsr[r] = -1; slotr[r] = 0;
+            if (r * kThreads < K) {                         // wave-uniform
+                const bool valid = p < K;
+                if (valid) {
+                    slotr[r] = (int)(key[p] & kSlotMask);
+                    clsr[r] = (int)((unsigned)cidx[slotr[r]] >> kSlotBits);
+                }
+                unsigned long long remaining = __ballot(valid);
+                while (remaining) {                         // one round per distinct class in this chunk
+                    const int leader = __builtin_ctzll(remaining);
+                    const int c0 = __builtin_amdgcn_readlane(clsr[r], leader);
+                    const unsigned long long m = __ballot(valid && clsr[r] == c0);
+                    if (valid && clsr[r] == c0) rankw[r] = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                    if (lane == leader) cnt[(wave + 4 * r) * 64 + c0] = (unsigned short)__builtin_popcountll(m);
+                    remaining &= ~m;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {                                     // per class: exclusive prefix over the chunks, total
+            int run = 0;
+            for (int ch = 0; ch < nchunks; ++ch) {
+                const int v = cnt[ch * 64 + tid];
+                cnt[ch * 64 + tid] = (unsigned short)run;
+                run += v;
+            }
+            int incl = run;                                 // exclusive scan over the 64 classes (this is wave 0)
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int v = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += v;
+            }
+            const int start = incl - run;
+            cstart_s[tid] = start;
+            const unsigned long long ne = __ballot(run > 0);
+            if (run > 0) segs[__builtin_popcountll(ne & ((1ull << lane) - 1ull))] = start;
+            if (tid == 0) ctl[2] = __builtin_popcountll(ne);
+        }
+        __syncthreads();
+        nseg = ctl[2];
+#pragma unroll
+        for (int r = 0; r < kMaxR; ++r) {
+            const int p = tid + r * kThreads;
+            if (p < K) cslot[cstart_s[clsr[r]] + cnt[(wave + 4 * r) * 64 + clsr[r]] + rankw[r]] = (unsigned short)slotr[r];
+        }
+        __syncthreads();
+    } else {
+    // segment starts in ascending order (ordered ballot compaction, as in phase A) -> lengths by subtraction
     for (int p0 = 0; p0 < K; p0 += kThreads) {
         const int p = p0 + tid;
         const bool st = p < K && (p == 0 || (key[p] >> kClsShift) != (key[p - 1] >> kClsShift));
@@ -429,6 +509,9 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
         par ^= 1;
     }
     __syncthreads();
+    }
+    // slot of the q-th box in class-major order
+    auto member = [&](int q) -> int { return onesort ? (int)cslot[q] : (int)(key[q] & kSlotMask); };
 
     // ---- C: greedy suppression per class segment ----
     // The textbook loop (for every kept box, test all later boxes) is one serial chain per segment and costs the same
@@ -477,7 +560,7 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
         while ((j + 1) * j / 2 <= r) ++j;
         const int i = r - j * (j - 1) / 2;             // 0 <= i < j < len
         const int p0 = seg_start(lo);
-        const float4 a = cbox[key[p0 + i] & kSlotMask], bq = cbox[key[p0 + j] & kSlotMask];
+        const float4 a = cbox[member(p0 + i)], bq = cbox[member(p0 + j)];
         const float v = yfs_iou_corners(a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w);
         if (v > g.iou_thr) atomicOr(&over[p0 + j], 1ull << i);
     }
@@ -491,7 +574,7 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
         for (int j = 0; j < len; ++j) {
             if ((over[p0 + j] & kept) == 0ull) {
                 kept |= 1ull << j;
-                kflag[key[p0 + j] & kSlotMask] = 1;
+                kflag[member(p0 + j)] = 1;
             }
         }
     }
@@ -510,13 +593,13 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
                 const unsigned hi32 = (unsigned)__shfl((int)(unsigned)(rem >> 32), own, 64);
                 const unsigned long long w = ((unsigned long long)hi32 << 32) | lo32;
                 if ((w >> ti) & 1ull) continue;
-                const int si = (int)(key[p0 + i] & kSlotMask);
+                const int si = member(p0 + i);
                 if (lane == 0) kflag[si] = 1;
                 const float4 pb = cbox[si];
                 for (int t = ti; t < T; ++t) {
                     const int j = lane + 64 * t;
                     if (j > i && j < len) {
-                        const float4 q = cbox[key[p0 + j] & kSlotMask];
+                        const float4 q = cbox[member(p0 + j)];
                         const float v = yfs_iou_corners(pb.x, pb.y, pb.z, pb.w, q.x, q.y, q.z, q.w);
                         if (v > g.iou_thr) rem |= 1ull << t;
                     }
@@ -527,7 +610,38 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
     if (tid == 0) ctl[1] = 0;
     __syncthreads();
 
-    // ---- D: kept boxes back in (score desc, index) order: drop the class field, sort once more ----
+    // ---- D: kept boxes in (score desc, index) order ----
+    int32_t* kp = g.keep + n * (int64_t)A;
+    if (onesort) {
+        // the array is already in output order: ordered compaction of the keep flags along it
+        int nk = 0;
+        for (int p0 = 0; p0 < K; p0 += kThreads) {
+            const int p = p0 + tid;
+            int slot = 0;
+            bool f = false;
+            if (p < K) {
+                slot = (int)(key[p] & kSlotMask);
+                f = kflag[slot] != 0;
+            }
+            const unsigned long long bal = __ballot(f);
+            if (lane == 0) wcnt[par][wave] = __builtin_popcountll(bal);
+            __syncthreads();
+            int off = nk, tot = 0;
+#pragma unroll
+            for (int w = 0; w < kThreads / 64; ++w) {
+                const int cw = wcnt[par][w];
+                off += w < wave ? cw : 0;
+                tot += cw;
+            }
+            if (f) kp[off + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = cidx[slot] & (int)kSlotMask;
+            nk += tot;
+            par ^= 1;
+        }
+        for (int i = nk + tid; i < A; i += kThreads) kp[i] = -1;
+        if (tid == 0) g.count[n] = nk;
+        return;
+    }
+    // class-major keys: drop the class field and sort once more
     for (int p0 = 0; p0 < ns; p0 += kThreads) {
         const int p = p0 + tid;
         bool f = false;
@@ -542,9 +656,7 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
     __syncthreads();
     const int nk = ctl[1];
     bitonic_sort(key, ns, tid);
-
-    int32_t* kp = g.keep + n * (int64_t)A;
-    for (int i = tid; i < A; i += kThreads) kp[i] = i < nk ? cidx[key[i] & kSlotMask] : -1;
+    for (int i = tid; i < A; i += kThreads) kp[i] = i < nk ? (cidx[key[i] & kSlotMask] & (int)kSlotMask) : -1;
     if (tid == 0) g.count[n] = nk;
 }
 
