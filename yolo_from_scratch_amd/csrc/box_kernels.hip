@@ -13,15 +13,22 @@ struct Decoded {
     int cls;
 };
 
+// The grid decode is VALU-bound: 25 exponentials per box (20 of them the softmax), ~20 instructions each with the
+// correctly rounded expf.  Decoded boxes and scores are compared with the oracle at 1e-5 relative (they go through libm
+// on the CPU side anyway, SURVEY.md 7 "hard parts"), and NMS parity is checked on the GPU's own decoded boxes, so the
+// decode uses the hardware exponential: exp2(x * log2 e), a few 1e-7 relative for |x| < 20.
+__device__ __forceinline__ float dec_exp(float x) { return __expf(x); }
+__device__ __forceinline__ float dec_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
 // raw (tx,ty,tw,th,to, C logits) at r[0..5+C), read with stride 1 from LDS.
 __device__ __forceinline__ Decoded decode_one(const float* r, int C, int row, int col, int S, float aw, float ah) {
     Decoded d;
     const float fS = (float)S;
-    d.x = (yfs_sigmoid(r[0]) + (float)col) / fS;
-    d.y = (yfs_sigmoid(r[1]) + (float)row) / fS;
-    d.w = aw * expf(r[2]) / fS;
-    d.h = ah * expf(r[3]) / fS;
-    const float conf = yfs_sigmoid(r[4]);
+    d.x = (dec_sigmoid(r[0]) + (float)col) / fS;
+    d.y = (dec_sigmoid(r[1]) + (float)row) / fS;
+    d.w = aw * dec_exp(r[2]) / fS;
+    d.h = ah * dec_exp(r[3]) / fS;
+    const float conf = dec_sigmoid(r[4]);
     float m = r[5];
     int best = 0;
     for (int c = 1; c < C; ++c) {
@@ -29,7 +36,7 @@ __device__ __forceinline__ Decoded decode_one(const float* r, int C, int row, in
         if (v > m) { m = v; best = c; }
     }
     float sum = 0.0f;
-    for (int c = 0; c < C; ++c) sum += expf(r[5 + c] - m);
+    for (int c = 0; c < C; ++c) sum += dec_exp(r[5 + c] - m);
     d.score = conf * (1.0f / sum);
     d.cls = best;
     return d;
@@ -202,11 +209,11 @@ __global__ void __launch_bounds__(kThreads) decode_grid_kernel(const float* __re
         score[b] = d.score;
         cls[b] = d.cls;
         if (all_scores) {
-            const float conf = yfs_sigmoid(r[4]);
+            const float conf = dec_sigmoid(r[4]);
             float m = r[5 + d.cls];
             float sum = 0.0f;
-            for (int c = 0; c < C; ++c) sum += expf(r[5 + c] - m);
-            for (int c = 0; c < C; ++c) all_scores[b * C + c] = conf * (expf(r[5 + c] - m) / sum);
+            for (int c = 0; c < C; ++c) sum += dec_exp(r[5 + c] - m);
+            for (int c = 0; c < C; ++c) all_scores[b * C + c] = conf * (dec_exp(r[5 + c] - m) / sum);
         }
     }
 }
