@@ -246,12 +246,23 @@ def stem_weight(w):
     return (flat[:, idx] * mask).to(torch.bfloat16).contiguous()
 
 
+def _stem_inverse(device):
+    """inv[j] = the one position k of w2's 256 columns that holds weight j of [7][7][3] (built once per device:
+    boolean-mask indexing here would run nonzero() and stall the host on the stream at every step)."""
+    key = ("inv", str(device))
+    if key not in _STEM_IDX:
+        idx, mask = _stem_index(device)
+        idx, mask = idx.cpu(), mask.cpu()
+        inv = torch.full((147,), -1, dtype=torch.long)
+        inv[idx[mask]] = torch.arange(256)[mask]
+        assert int(inv.min()) >= 0
+        _STEM_IDX[key] = inv.to(device)
+    return _STEM_IDX[key]
+
+
 def stem_weight_grad(dw2, cout):
     """dw2 fp32 [Cout, 256] -> gradient in [Cout, 147] ((kh,kw,c) order): every real weight appears once in w2."""
-    idx, mask = _stem_index(dw2.device)
-    out = torch.zeros(cout, 147, device=dw2.device, dtype=torch.float32)
-    out[:, idx[mask]] = dw2.view(cout, 256)[:, mask]
-    return out
+    return dw2.view(cout, 256)[:, _stem_inverse(dw2.device)]
 
 
 def stem_fwd(xs, w2, bias, oh, ow, slope=0.1):
