@@ -280,7 +280,9 @@ def train_one_epoch(model, loader, device, opt, scaler, loss_fn, max_norm=1.0):
     """Same call and return as the reference.  The model computes in bf16 internally, so ``scaler`` may be a
     disabled GradScaler (or None); an enabled one still works (bf16 has fp32's exponent range)."""
     model.train()
-    running = 0.0
+    # The reference adds loss.item() every batch (:337), which stalls the host on the stream each step; the same
+    # sum is kept on the device in fp64 (what the Python float sum is) and read once at the end of the epoch.
+    running = torch.zeros((), dtype=torch.float64, device=device)
     n = 0
     flat = isinstance(opt, FlatSGD)
     # A generation-2 garbage collection walks every object torch created at import (~75 ms) while the GPU idles;
@@ -308,6 +310,6 @@ def train_one_epoch(model, loader, device, opt, scaler, loss_fn, max_norm=1.0):
                 if max_norm is not None:
                     nn.utils.clip_grad_norm_(model.parameters(), max_norm)
                 opt.step()
-        running += loss.item() * xb.size(0)
+        running += loss.detach().double() * xb.size(0)
         n += xb.size(0)
-    return running / n
+    return running.item() / n
