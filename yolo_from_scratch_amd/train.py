@@ -260,7 +260,7 @@ def grad_ready(param):
 @torch.no_grad()
 def evaluate(model, loader, device, loss_fn):
     model.eval()
-    total_loss = 0.0
+    total_loss = torch.zeros((), dtype=torch.float64, device=device)   # summed on the device: see train_one_epoch
     total_iou = 0.0
     n = 0
     for xb, yb in loader:
@@ -268,11 +268,11 @@ def evaluate(model, loader, device, loss_fn):
         yb = yb.to(device, non_blocking=True)
         preds = model(xb)
         loss = loss_fn(preds, yb)
-        total_loss += loss.item() * xb.size(0)
+        total_loss += loss.detach().double() * xb.size(0)
         if preds.dim() == 2 and preds.shape[1] == 4:
             total_iou += iou_xywh_torch(preds, yb) * xb.size(0)
         n += xb.size(0)
-    return total_loss / n, total_iou / n
+    return total_loss.item() / n, total_iou / n
 
 
 # ---- yolo_toy_regressor_torch.py:314-339 --------------------------------------------------------
