@@ -100,7 +100,8 @@ def test_fused_linear_module_train_eval_and_gradients():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("b,n_in,n_out,first,clip", [(64, 512, 256, True, False), (64, 1280, 384, False, True),
-                                                     (20, 256, 128, False, False), (130, 384, 256, False, True)])
+                                                     (20, 256, 128, False, False), (130, 384, 256, False, True),
+                                                     (512, 256, 256, False, True)])   # 512 rows: the 8-GPU gathered step
 def test_linear_wgrad_fused_with_sgd_step(b, n_in, n_out, first, clip):
     """yfs_linear_wgrad_sgd_bf16 == (dW = dy^T x in fp32 from the bf16 operands) followed by the clip + SGD formula of
     yolo_toy_regressor_torch.py:331-335, :378-381, to fp32 summation-order tolerance; the bf16 shadow is the rounding of

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from yolo_from_scratch_amd import fc_ops as fo, _lib as L
 import bench
 dev = "cuda:0"
-B, I, O = 64, 50176, 4096
+B, I, O = int(os.environ.get("FC_B", "64")), 50176, 4096   # FC_B=512: the 8-GPU step (factors of 8 ranks gathered)
 x = torch.randn(B, I, device=dev).bfloat16(); dy = (torch.randn(B, O, device=dev) * 0.01).bfloat16()
 p = torch.randn(O, I, device=dev) * 0.01; m = torch.zeros_like(p); g = torch.empty_like(p); p16 = p.bfloat16()
 ss = torch.ones(1, device=dev)
@@ -21,4 +21,4 @@ def new():
     g1 = torch.mm(dy, dy.t(), out_dtype=torch.float32); g2 = torch.mm(x, x.t(), out_dtype=torch.float32)
     s = (g1 * g2).sum().reshape(1)
     fo.linear_wgrad_sgd(x, dy, p, m, p16, s, 1.0, 1e-3, 0.9, 5e-4, False)
-print(f"materialised: {bench._time_ms(old, 10):.3f} ms | fused: {bench._time_ms(new, 10):.3f} ms")
+print(f"B={B} materialised: {bench._time_ms(old, 10):.3f} ms | fused: {bench._time_ms(new, 10):.3f} ms")
