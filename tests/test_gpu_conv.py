@@ -233,3 +233,47 @@ def test_stem_wgrad_from_pooled_side(n, hw, cout, leaky):
     dw, db = co.stem_wgrad_pool(xs, gp, idx, yp if leaky else None)
     assert float((dw - dw_ref).abs().max()) <= 1e-5 * float(dw_ref.abs().max()) + 1e-6
     assert float((db - db_ref).abs().max()) <= 1e-5 * float(db_ref.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("tile", ["224", "2562"])
+def test_big_igemm_tiles_are_bit_identical_to_the_default(tile):
+    """The 224x256 and 256x256 workgroup tiles are picked by a round-count model that only fires at full-size layers
+    (and in tests/test_gpu_model.py's config-2 case); YFS_IGEMM_TILE forces one, read once per process, so a child
+    process runs forward, pool-fused forward and masked dgrad on ragged shapes (M not a multiple of the tile) with the
+    forced tile.  Every output element accumulates the same K-steps in the same order whatever the tile, so the results
+    must equal the default 128x128 tile's bit for bit."""
+    import subprocess
+    import sys
+    import tempfile
+    code = (
+        "import sys, numpy as np, torch\n"
+        "from yolo_from_scratch_amd import conv_ops as co\n"
+        "outs = []\n"
+        "for n, cin, cout, k, hw in [(3, 64, 256, 3, 15), (2, 128, 512, 1, 14), (1, 64, 256, 3, 30)]:\n"
+        "    g = torch.Generator().manual_seed(cin + hw)\n"
+        "    x = co.nhwc((torch.rand(n, cin, hw, hw, generator=g) - 0.3).cuda(), torch.bfloat16)\n"
+        "    w = co.nhwc(((torch.rand(cout, cin, k, k, generator=g) * 2 - 1) / (cin * k * k) ** 0.5).cuda())\n"
+        "    b = ((torch.rand(cout, generator=g) * 2 - 1) * 0.1).cuda()\n"
+        "    w16, wt16 = co.weight_prep(w)\n"
+        "    y = co.conv_fwd(x, w16, b, 1)\n"
+        "    outs.append(y)\n"
+        "    if hw % 2 == 0:\n"
+        "        outs.extend(co.conv_fwd_pool(x, w16, b, 1))\n"
+        "    act = co.nhwc(torch.randn(n, cout, hw, hw, generator=g).cuda(), torch.bfloat16)\n"
+        "    w2 = co.nhwc(((torch.rand(cout, cout, k, k, generator=g) * 2 - 1) / (cout * k * k) ** 0.5).cuda())\n"
+        "    outs.append(co.conv_dgrad(y, co.weight_prep(w2)[1], (hw, hw), 1, x_act=act))\n"
+        "np.savez(sys.argv[1], *[t.float().cpu().numpy() for t in outs])\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        res = {}
+        for name, force in (("default", None), ("forced", tile)):
+            env = dict(os.environ, PYTHONPATH=root)
+            env.pop("YFS_IGEMM_TILE", None)
+            if force:
+                env["YFS_IGEMM_TILE"] = force
+            path = os.path.join(d, name + ".npz")
+            subprocess.run([sys.executable, "-c", code, path], check=True, env=env, cwd=root, timeout=110)
+            res[name] = np.load(path)
+        assert len(res["default"].files) == 10
+        for key in res["default"].files:
+            np.testing.assert_array_equal(res["forced"][key], res["default"][key])

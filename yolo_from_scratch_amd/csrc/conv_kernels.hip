@@ -109,11 +109,13 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) igemm_kernel(IgemmArgs g) {
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int FP = BM / WM / 16;   // pixel fragments per wave
     constexpr int FC = BN / WN / 16;   // channel fragments per wave
-    constexpr int RA = BM / 8 / NW;    // LDS-DMA instructions per wave per tile, pixel operand (8 rows each)
+    constexpr int RA = (BM / 8 + NW - 1) / NW;   // LDS-DMA instructions per wave per tile, pixel operand (8 rows each)
+    constexpr bool RAGGED_A = (BM / 8) % NW != 0;   // BM = 224: 28 row groups over 8 waves, the last wave stages none
     constexpr int RB = BN / 8 / NW;    // ... weight operand
     constexpr int TILE_BYTES = (BM + BN) * 128;
     constexpr int EPI_STRIDE = BN * 4 + 16;
-    static_assert(RA >= 1 && RB >= 1 && STAGES >= 2 && STAGES <= 3, "unsupported igemm configuration");
+    static_assert(RA >= 1 && RB >= 1 && STAGES >= 2 && STAGES <= 3 && BM % 8 == 0 && (BM / WM) % 16 == 0 && (!RAGGED_A || STAGES == 2),
+                  "unsupported igemm configuration");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -195,6 +197,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) igemm_kernel(IgemmArgs g) {
         const unsigned wk = SUB ? (unsigned)(((kh * g.KW + kw) * g.C + cc * BK) * 2) : (unsigned)it * (BK * 2);
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
+            if (RAGGED_A && (wave_u * RA + i) * 8 >= BM) continue;   // wave-uniform: no row group here
             const int sh = bh[i] + dh, sw = bw[i] + dw;
             const bool ok = (unsigned)sh < (unsigned)g.H && (unsigned)sw < (unsigned)g.W;
             const unsigned off = rowbyte[i] + tapoff;
@@ -413,22 +416,29 @@ int launch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
 // the 192-channel outputs (stem + pool 584 vs 571 us, feat.2 dgrad 759 vs 738 us: no gain), a 3-deep ring for grids of
 // at most one workgroup per CU (feat.25-27, 200 tiles: 101 vs 96 us — a lone workgroup is not latency-bound either: its
 // 32 KiB per K-step at ~31 B/clk is 1060 of the 1390 cycles a step takes, the same per-CU staging limit as with two).
-// 128x192 serves the 192-channel outputs (pixel tile read once instead of three times with 128x64).  YFS_IGEMM_TILE=128|256|2562 forces a variant for benchmarking.
+// 128x192 serves the 192-channel outputs (pixel tile read once instead of three times with 128x64).  YFS_IGEMM_TILE=128|256|2562|224 forces a variant for benchmarking.
 template <int EPI, bool SUB>
 int dispatch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
     static const int force = [] { const char* e = getenv("YFS_IGEMM_TILE"); return e ? atoi(e) : 0; }();
     if (g.NOUT % 192 == 0 && g.NOUT % 128 != 0 && force != 64) return launch_igemm<128, 192, 2, 2, 2, EPI, SUB>(g, s, name);
     if (g.NOUT % 128 != 0) return launch_igemm<128, 64, 2, 2, 2, EPI, SUB>(g, s, name);
     if (force == 256) return launch_igemm<256, 128, 4, 2, 3, EPI, SUB>(g, s, name);
-    bool big = force == 2562;
+    bool big = force == 2562 || force == 224, rows224 = force == 224;
     if (force == 0 && !SUB) {
         // rounds x time per round: 128x128 runs 512 tiles per round (2 per CU) in 2u, 256x256 runs 256 tiles per
         // round in 4u / 1.18 (its measured per-CU advantage); take the big tile when that wins by >= 10 %.
+        // 224x256 is the same kernel with 7 instead of 8 pixel fragments per wave: every M of this network is
+        // 64 * (7 * 2^k)^2, so 224-row tiles have no ragged edge and their counts (224, 448, 896, ...) fill 256 CUs to
+        // 87.5 % where 196 / 392 tiles of 256 rows fill 76.6 %.
         const long long t128 = yfs_cdiv(g.M, 128) * (g.NOUT / 128), t256 = yfs_cdiv(g.M, 256) * yfs_cdiv(g.NOUT, 256);
+        const long long t224 = yfs_cdiv(g.M, 224) * yfs_cdiv(g.NOUT, 256);
         const double c128 = (double)yfs_cdiv(t128, 512) * 2.0, c256 = (double)yfs_cdiv(t256, 256) * (4.0 / 1.18);
-        big = c256 < 0.9 * c128 && g.KH * g.KW * g.C >= 1728;   // (shorter K: the four-pass epilogue eats the gain)
+        const double c224 = (double)yfs_cdiv(t224, 256) * (4.0 / 1.18) * (224.0 / 256.0);
+        rows224 = c224 < c256;
+        big = (rows224 ? c224 : c256) < 0.9 * c128 && g.KH * g.KW * g.C >= 1728;   // (shorter K: the epilogue passes eat the gain; 224 rows at K >= 1152 or 512: no change)
     }
-    if (big && g.NOUT % 256 == 0) return launch_igemm<256, 256, 2, 4, 2, EPI, SUB>(g, s, name);
+    if (big && g.NOUT % 256 == 0)
+        return rows224 ? launch_igemm<224, 256, 2, 4, 2, EPI, SUB>(g, s, name) : launch_igemm<256, 256, 2, 4, 2, EPI, SUB>(g, s, name);
     return launch_igemm<128, 128, 2, 2, 2, EPI, SUB>(g, s, name);
 }
 
