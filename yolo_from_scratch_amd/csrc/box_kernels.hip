@@ -286,6 +286,7 @@ struct NmsArgs {
 constexpr int kSlotBits = 11;                 // YFS_NMS_MAX_BOXES = 2048
 constexpr unsigned long long kSlotMask = (1ull << kSlotBits) - 1ull;
 constexpr int kClsShift = 32 + kSlotBits;
+constexpr int kQShift = kSlotBits + 6;      // one-sort path (class < 64): cidx = [class-major position:11 | class:6 | box index:11]
 __device__ __forceinline__ unsigned score_bits(float s) {
     unsigned u = __float_as_uint(s);
     u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // monotone float -> uint
@@ -313,6 +314,12 @@ __device__ __forceinline__ void bitonic_sort(unsigned long long* a, int n, int t
     }
 }
 
+#ifdef YFS_NMS_TIMING
+__device__ long long yfs_nms_dbg[2][16];
+#define NMS_T(k) do { if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 517)) yfs_nms_dbg[blockIdx.x != 0][k] = clock64(); } while (0)
+#else
+#define NMS_T(k) do { } while (0)
+#endif
 template <bool FUSED>
 __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -332,6 +339,7 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
     unsigned long long* over = reinterpret_cast<unsigned long long*>(tail + 8 * (size_t)cap);  // 8*cap  overlap masks
     float* rawlds = reinterpret_cast<float*>(tail);   // fused: raw-head staging, dead before kflag / segs are used
 
+    NMS_T(0);
     // ---- A: decode / filter, candidates compacted in box-index order (ballot prefix, no atomics) ----
     int K = 0;
     int par = 0;
@@ -432,12 +440,14 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
     int ns = 2;
     while (ns < K) ns <<= 1;                       // K <= cap <= npow
     __syncthreads();
+    NMS_T(1);
     const bool onesort = ctl[0] < 64 && cap >= 128;   // (cslot sits behind 64 segment starts inside the 4*cap segs region)
     for (int p = K + tid; p < ns; p += kThreads) key[p] = ~0ull;
     if (onesort)
         for (int p = tid; p < K; p += kThreads) key[p] &= (1ull << kClsShift) - 1ull;
     __syncthreads();
     bitonic_sort(key, ns, tid);
+    NMS_T(2);
     int nseg = 0;
     unsigned short* cslot = reinterpret_cast<unsigned short*>(segs + 64);   // onesort: slot of the q-th box, class-major
     if (onesort) {
@@ -493,7 +503,11 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
 #pragma unroll
         for (int r = 0; r < kMaxR; ++r) {
             const int p = tid + r * kThreads;
-            if (p < K) cslot[cstart_s[clsr[r]] + cnt[(wave + 4 * r) * 64 + clsr[r]] + rankw[r]] = (unsigned short)slotr[r];
+            if (p < K) {
+                const int q = cstart_s[clsr[r]] + cnt[(wave + 4 * r) * 64 + clsr[r]] + rankw[r];
+                cslot[q] = (unsigned short)slotr[r];
+                cidx[slotr[r]] |= q << kQShift;     // [q:11 | class:6 | box index:11]: phase D finds the keep flag of a slot
+            }
         }
         __syncthreads();
     } else {
@@ -523,24 +537,31 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
     // ---- C: greedy suppression per class segment ----
     // The textbook loop (for every kept box, test all later boxes) is one serial chain per segment and costs the same
     // ~45 VALU per step whether 5 or 64 lanes hold a member: with ~23 members per class most lanes idle.  Instead:
-    //   C1  every (earlier i, later j) pair of every segment of <= 64 members is one work item, spread over all 256
-    //       threads: segment by binary search over the prefix sums of pair counts, (i, j) from the triangular index;
-    //       an overlap above the threshold sets bit i of over[j] (LDS atomic OR);
-    //   C2  one thread per segment walks its members in score order: j survives iff no surviving earlier member
-    //       overlaps it, (over[j] & kept) == 0 — exactly the greedy rule, now a chain of one AND per member.
+    //   C1  the overlap bitmask of every member: over[j] bit i = (IoU(i, j) > threshold) for the earlier members i < j of
+    //       its segment (segments of <= 64 members).  All (i, j) pairs of all segments form one index space; every thread
+    //       takes a contiguous run of it (one binary search over prefix sums of pair counts + one triangular-root, then
+    //       (i, j) advance incrementally), so the ~5 K IoUs of an image are spread evenly over the 256 threads whatever
+    //       the class histogram is; the bits of one j are collected in a register and published with one LDS atomic OR.
+    //       The phase is VALU-issue-bound (~50 instructions per pair, 4 cycles each per wave), so balance is what
+    //       counts: per-pair work items (search + root per pair) took 36 K cycles, rows t and len-1-t of a segment as
+    //       one item (no atomics, but the longest segment sets the trip count of its wave) 20-28 K, this form 18-25 K.
     // Segments longer than 64 keep the wave-per-segment loop.
-    int* ppre = kflag;   // [nseg] exclusive prefix sums of pair counts; the region becomes the keep flags after C1
+    NMS_T(3);
+    int* ppre = kflag;   // [nseg] exclusive prefix sums of item counts; the region becomes the keep flags after C1
     auto seg_start = [&](int sgi) { return segs[sgi]; };
     auto seg_length = [&](int sgi) { return (sgi + 1 < nseg ? segs[sgi + 1] : K) - segs[sgi]; };
-    if (wave == 0) {     // exclusive scan of the pair counts, 64 segments per round
-        int carry = 0;
+    if (wave == 0) {     // exclusive scan of the pair counts, 64 segments per round; number of long segments
+        int carry = 0, nl = 0;
         for (int s0 = 0; s0 < nseg; s0 += 64) {
             const int sgi = s0 + lane;
             int cnt = 0;
+            bool lng = false;
             if (sgi < nseg) {
                 const int len = seg_length(sgi);
                 cnt = len <= 64 ? len * (len - 1) / 2 : 0;
+                lng = len > 64;
             }
+            nl += __builtin_popcountll(__ballot(lng));
             int incl = cnt;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
@@ -550,42 +571,67 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
             if (sgi < nseg) ppre[sgi] = carry + incl - cnt;
             carry += __shfl(incl, 63, 64);
         }
-        if (lane == 0) ctl[3] = carry;   // total number of pairs
+        if (lane == 0) { ctl[3] = carry; ctl[2] = nl; }   // total number of pairs; long segments (ctl[2] was nseg: consumed)
     }
     for (int p = tid; p < K; p += kThreads) over[p] = 0ull;
     __syncthreads();
+    NMS_T(4);
     const int P = ctl[3];
-    for (int q = tid; q < P; q += kThreads) {
-        int lo = 0, hi = nseg;                       // last segment with ppre <= q (empty ones share their successor's value)
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (ppre[mid] <= q) lo = mid; else hi = mid;
-        }
-        const int r = q - ppre[lo];
-        int j = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)r)) * 0.5f);
-        while (j * (j - 1) / 2 > r) --j;
-        while ((j + 1) * j / 2 <= r) ++j;
-        const int i = r - j * (j - 1) / 2;             // 0 <= i < j < len
-        const int p0 = seg_start(lo);
-        const float4 a = cbox[member(p0 + i)], bq = cbox[member(p0 + j)];
-        const float v = yfs_iou_corners(a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w);
-        if (v > g.iou_thr) atomicOr(&over[p0 + j], 1ull << i);
-    }
-    __syncthreads();
-    for (int p = tid; p < K; p += kThreads) kflag[p] = 0;     // (was ppre)
-    __syncthreads();
-    for (int sgi = tid; sgi < nseg; sgi += kThreads) {
-        const int p0 = seg_start(sgi), len = seg_length(sgi);
-        if (len > 64) continue;
-        unsigned long long kept = 0;
-        for (int j = 0; j < len; ++j) {
-            if ((over[p0 + j] & kept) == 0ull) {
-                kept |= 1ull << j;
-                kflag[member(p0 + j)] = 1;
+    {
+        const int run = (P + kThreads - 1) / kThreads;
+        int q = tid * run;
+        const int qend = q + run < P ? q + run : P;
+        if (q < qend) {
+            int lo = 0, hi = nseg;                   // last segment with ppre <= q (empty ones share their successor's value)
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (ppre[mid] <= q) lo = mid; else hi = mid;
+            }
+            const int r = q - ppre[lo];
+            int j = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)r)) * 0.5f);
+            while (j * (j - 1) / 2 > r) --j;
+            while ((j + 1) * j / 2 <= r) ++j;
+            int i = r - j * (j - 1) / 2;               // 0 <= i < j < len
+            int p0 = seg_start(lo), len = seg_length(lo);
+            float4 bq = cbox[member(p0 + j)];
+            unsigned bits_lo = 0u, bits_hi = 0u;     // overlaps found for the current j
+            for (;;) {
+                const float4 a = cbox[member(p0 + i)];
+                const float v = yfs_iou_corners(a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w);
+                if (v > g.iou_thr) {
+                    bits_lo |= i < 32 ? 1u << i : 0u;
+                    bits_hi |= i < 32 ? 0u : 1u << (i - 32);
+                }
+                const bool last = ++q == qend;
+                if (++i == j || last) {              // leaving this j: publish its bits (other threads may hold part of it)
+                    const unsigned long long bits = ((unsigned long long)bits_hi << 32) | bits_lo;
+                    if (bits) atomicOr(&over[p0 + j], bits);
+                    bits_lo = bits_hi = 0u;
+                    if (last) break;
+                    i = 0;
+                    if (++j == len) {                // next segment that has pairs (exists: q < P)
+                        do { ++lo; len = seg_length(lo); } while (len < 2 || len > 64);
+                        p0 = seg_start(lo);
+                        j = 1;
+                    }
+                    bq = cbox[member(p0 + j)];
+                }
             }
         }
     }
-    {   // long segments: one wave each; member lane + 64 t <-> bit t of this lane's `rem`
+    __syncthreads();
+    NMS_T(5);
+    // keep flags, indexed by class-major position (the same index as `over`)
+    for (int sgi = tid; sgi < nseg; sgi += kThreads) {
+        const int p0 = seg_start(sgi), len = seg_length(sgi);
+        if (len > 64) continue;                      // the wave loop below owns these
+        unsigned long long kept = 0;
+#pragma unroll 4
+        for (int j = 0; j < len; ++j)                // loads only: independent of `kept`, so they are issued ahead
+            if ((over[p0 + j] & kept) == 0ull) kept |= 1ull << j;
+        for (int j = 0; j < len; ++j) kflag[p0 + j] = (int)((kept >> j) & 1ull);
+    }
+    if (ctl[2] > 0) {   // long segments (rare): one wave each; member lane + 64 t <-> bit t of this lane's `rem`
         int nlong = 0;
         for (int sgi = 0; sgi < nseg; ++sgi) {
             const int len = seg_length(sgi);
@@ -593,6 +639,7 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
             if ((nlong++ & (kThreads / 64 - 1)) != wave) continue;
             const int p0 = seg_start(sgi);
             const int T = (len + 63) >> 6;
+            for (int j = lane; j < len; j += 64) kflag[p0 + j] = 0;   // (same wave as the writes of 1 below: in order)
             unsigned long long rem = 0;
             for (int i = 0; i < len; ++i) {
                 const int ti = i >> 6, own = i & 63;
@@ -601,7 +648,7 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
                 const unsigned long long w = ((unsigned long long)hi32 << 32) | lo32;
                 if ((w >> ti) & 1ull) continue;
                 const int si = member(p0 + i);
-                if (lane == 0) kflag[si] = 1;
+                if (lane == 0) kflag[p0 + i] = 1;
                 const float4 pb = cbox[si];
                 for (int t = ti; t < T; ++t) {
                     const int j = lane + 64 * t;
@@ -616,6 +663,7 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
     }
     if (tid == 0) ctl[1] = 0;
     __syncthreads();
+    NMS_T(6);
 
     // ---- D: kept boxes in (score desc, index) order ----
     int32_t* kp = g.keep + n * (int64_t)A;
@@ -628,7 +676,7 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
             bool f = false;
             if (p < K) {
                 slot = (int)(key[p] & kSlotMask);
-                f = kflag[slot] != 0;
+                f = kflag[(unsigned)cidx[slot] >> kQShift] != 0;
             }
             const unsigned long long bal = __ballot(f);
             if (lane == 0) wcnt[par][wave] = __builtin_popcountll(bal);
@@ -646,6 +694,7 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
         }
         for (int i = nk + tid; i < A; i += kThreads) kp[i] = -1;
         if (tid == 0) g.count[n] = nk;
+        NMS_T(7);
         return;
     }
     // class-major keys: drop the class field and sort once more
@@ -654,7 +703,7 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
         bool f = false;
         if (p < ns) {
             const unsigned long long k = key[p];
-            f = p < K && kflag[k & kSlotMask] != 0;
+            f = p < K && kflag[p] != 0;
             key[p] = f ? (k & ((1ull << kClsShift) - 1ull)) : ~0ull;
         }
         const unsigned long long bal = __ballot(f);
@@ -836,3 +885,9 @@ YFS_API int yfs_decode_nms_f32(const float* raw, int64_t N, int S, int A, int C,
     YFS_CHECK_LAUNCH("nms_kernel<fused>");
     return YFS_OK;
 }
+
+#ifdef YFS_NMS_TIMING
+YFS_API int yfs_debug_nms_times(long long* host32) {
+    return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(yfs_nms_dbg), sizeof(long long) * 32);
+}
+#endif
