@@ -107,6 +107,9 @@ def _nms_case(N, A, seed, ncls=20, pass_frac=0.15, tie=False, clustered=False):
     (3, 845, {"ncls": 200}), (2, 300, {"ncls": 70, "clustered": True, "pass_frac": 0.8}),
     # exactly 64 classes (largest id 63): still the one-sort path; one class only
     (2, 845, {"ncls": 64, "clustered": True}), (2, 500, {"ncls": 1, "pass_frac": 0.1}),
+    # 257..512 and 513..1024 candidates: the register-resident sorts (2 and 4 keys per thread), with score ties
+    (3, 845, {"tie": True, "pass_frac": 0.5}), (2, 845, {"tie": True, "pass_frac": 0.9, "clustered": True}),
+    (2, 600, {"pass_frac": 0.45, "clustered": True}), (2, 1024, {"pass_frac": 1.0, "ncls": 5}),
 ])
 def test_nms_kept_indices_bit_exact(N, A, kw):
     boxes, score, cls = _nms_case(N, A, seed=N * 7 + A, **kw)

@@ -314,6 +314,60 @@ __device__ __forceinline__ void bitonic_sort(unsigned long long* a, int n, int t
     }
 }
 
+// The same sort for n = 256 * 2^LR keys with the keys in registers: thread t holds elements t*R .. t*R+R-1 (R = 2^LR),
+// so exchange distances below R stay inside a thread, distances R .. 32R are lane exchanges inside a wave (no LDS
+// traffic, no barrier) and only the distances 64R and 128R (3 of the 45 steps at n = 512) go through LDS.  The LDS
+// version is VALU-issue-bound (index arithmetic, two reads, two predicated writes and a barrier per step for every
+// wave); this one issues about half the instructions.  Same result: the keys are unique, so ascending order is unique.
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int lane_mask) {
+    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, lane_mask, 64);
+    const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), lane_mask, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+template <int LR>
+__device__ __forceinline__ void bitonic_sort_regs(unsigned long long* a, int tid) {
+    constexpr int R = 1 << LR, n = kThreads * R;
+    const int base = tid * R;
+    unsigned long long v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = a[base + r];
+#pragma unroll
+    for (int k = 2; k <= n; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j < R) {                                  // inside the thread
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (r & j) continue;
+                    const bool up = k == n || ((base + r) & k) == 0;
+                    const unsigned long long x = v[r], y = v[r | j];
+                    if ((x > y) == up) { v[r] = y; v[r | j] = x; }
+                }
+            } else {
+                const bool cross_wave = j >= 64 * R;
+                if (cross_wave) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) a[base + r] = v[r];
+                    __syncthreads();
+                }
+                const bool lower = (base & j) == 0;          // (j >= R: the same for all r of a thread)
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const bool up = k == n || ((base + r) & k) == 0;
+                    const unsigned long long y = cross_wave ? a[(base + r) ^ j] : shfl_xor_u64(v[r], j >> LR);
+                    const bool take_min = lower == up;
+                    const bool y_less = y < v[r];
+                    v[r] = (y_less == take_min) ? y : v[r];
+                }
+                if (cross_wave) __syncthreads();             // partners read before the next cross-wave step overwrites
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) a[base + r] = v[r];
+    __syncthreads();
+}
+
 #ifdef YFS_NMS_TIMING
 __device__ long long yfs_nms_dbg[2][16];
 #define NMS_T(k) do { if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 517)) yfs_nms_dbg[blockIdx.x != 0][k] = clock64(); } while (0)
@@ -446,7 +500,9 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
     if (onesort)
         for (int p = tid; p < K; p += kThreads) key[p] &= (1ull << kClsShift) - 1ull;
     __syncthreads();
-    bitonic_sort(key, ns, tid);
+    if (ns == kThreads * 2) bitonic_sort_regs<1>(key, tid);          // block-uniform
+    else if (ns == kThreads * 4) bitonic_sort_regs<2>(key, tid);
+    else bitonic_sort(key, ns, tid);
     NMS_T(2);
     int nseg = 0;
     unsigned short* cslot = reinterpret_cast<unsigned short*>(segs + 64);   // onesort: slot of the q-th box, class-major
