@@ -523,14 +523,18 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
                     slotr[r] = (int)(key[p] & kSlotMask);
                     clsr[r] = (int)((unsigned)cidx[slotr[r]] >> kSlotBits);
                 }
-                unsigned long long remaining = __ballot(valid);
-                while (remaining) {                         // one round per distinct class in this chunk
-                    const int leader = __builtin_ctzll(remaining);
-                    const int c0 = __builtin_amdgcn_readlane(clsr[r], leader);
-                    const unsigned long long m = __ballot(valid && clsr[r] == c0);
-                    if (valid && clsr[r] == c0) rankw[r] = __builtin_popcountll(m & ((1ull << lane) - 1ull));
-                    if (lane == leader) cnt[(wave + 4 * r) * 64 + c0] = (unsigned short)__builtin_popcountll(m);
-                    remaining &= ~m;
+                // lanes of the chunk that hold the same class: six ballots (one per class bit) instead of one round per
+                // distinct class (~19 rounds of readlane + ballot for 64 boxes in 20 classes)
+                unsigned long long m = __ballot(valid);
+#pragma unroll
+                for (int b = 0; b < 6; ++b) {
+                    const bool bit = (clsr[r] >> b) & 1;
+                    const unsigned long long bal = __ballot(valid && bit);
+                    m &= bit ? bal : ~bal;
+                }
+                if (valid) {
+                    rankw[r] = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                    if (rankw[r] == 0) cnt[(wave + 4 * r) * 64 + clsr[r]] = (unsigned short)__builtin_popcountll(m);
                 }
             }
         }
