@@ -297,6 +297,24 @@ __device__ __forceinline__ unsigned long long make_key(int cls, float s, int slo
            (unsigned)slot;
 }
 
+// yfs_iou_corners for the suppression loop, which is VALU-issue-bound: fminf / fmaxf on values that come back from LDS
+// make the compiler canonicalise every operand first (8 extra instructions per pair); the hardware min / max already
+// implement minNum / maxNum (the non-NaN operand, signalling NaNs quieted), so they are issued directly.  Same op order,
+// same results.
+__device__ __forceinline__ float hw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float nms_pair_iou(const float4 p, const float4 q) {
+    float iw = hw_min(p.z, q.z) - hw_max(p.x, q.x);
+    float ih = hw_min(p.w, q.w) - hw_max(p.y, q.y);
+    iw = iw > 0.0f ? iw : 0.0f;
+    ih = ih > 0.0f ? ih : 0.0f;
+    const float inter = iw * ih;
+    const float ap = (p.z - p.x) * (p.w - p.y);
+    const float ag = (q.z - q.x) * (q.w - q.y);
+    const float uni = ap + ag - inter;
+    return uni > 0.0f ? inter / uni : 0.0f;
+}
+
 // In-place ascending bitonic sort of n = 2^k 64-bit keys in LDS by the whole workgroup (one compare-exchange per
 // thread and step; n log^2 n / 4 exchanges instead of the n^2 compares of a rank sort).
 __device__ __forceinline__ void bitonic_sort(unsigned long long* a, int n, int tid) {
@@ -654,19 +672,15 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
             int i = r - j * (j - 1) / 2;               // 0 <= i < j < len
             int p0 = seg_start(lo), len = seg_length(lo);
             float4 bq = cbox[member(p0 + j)];
-            unsigned bits_lo = 0u, bits_hi = 0u;     // overlaps found for the current j
+            unsigned long long bits = 0ull;          // overlaps found for the current j
             for (;;) {
                 const float4 a = cbox[member(p0 + i)];
-                const float v = yfs_iou_corners(a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w);
-                if (v > g.iou_thr) {
-                    bits_lo |= i < 32 ? 1u << i : 0u;
-                    bits_hi |= i < 32 ? 0u : 1u << (i - 32);
-                }
+                const float v = nms_pair_iou(a, bq);
+                if (v > g.iou_thr) bits |= 1ull << i;
                 const bool last = ++q == qend;
                 if (++i == j || last) {              // leaving this j: publish its bits (other threads may hold part of it)
-                    const unsigned long long bits = ((unsigned long long)bits_hi << 32) | bits_lo;
                     if (bits) atomicOr(&over[p0 + j], bits);
-                    bits_lo = bits_hi = 0u;
+                    bits = 0ull;
                     if (last) break;
                     i = 0;
                     if (++j == len) {                // next segment that has pairs (exists: q < P)
