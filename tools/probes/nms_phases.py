@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase timing of nms_kernel (needs libyfs_dbg.so built with -DYFS_NMS_TIMING; see the NMS_T marks in box_kernels.hip).
+"""Phase timing of nms_kernel (needs libyfs_dbg.so: `make -C yolo_from_scratch_amd/csrc nms-timing`; see the NMS_T marks in box_kernels.hip).
 Prints core-clock cycles between the marks for workgroups 0 and 517 of a 1024-image launch (config 4)."""
 import ctypes, os, sys, torch
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,7 +22,7 @@ for it in range(3):
     torch.cuda.synchronize()
 buf = (ctypes.c_longlong * 32)()
 assert lib.yfs_debug_nms_times(buf) == 0
-names = ["A filter", "maxcls+pad", "bitonic sort", "counting sort", "pair prefix", "C1 pairs", "C2 resolve", "D output"]
+names = ["A filter", "pad + sort", "counting sort", "pair prefix", "C1 pair IoUs", "C2 resolve", "D output"]
 for b in range(2):
     t = [buf[b * 16 + k] for k in range(8)]
     print("block", (0, 517)[b], "total", t[7] - t[0], "cycles:", ", ".join(f"{names[k]} {t[k + 1] - t[k]}" if k < 7 else "" for k in range(7)))
