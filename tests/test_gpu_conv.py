@@ -235,7 +235,7 @@ def test_stem_wgrad_from_pooled_side(n, hw, cout, leaky):
     assert float((db - db_ref).abs().max()) <= 1e-5 * float(db_ref.abs().max()) + 1e-6
 
 
-@pytest.mark.parametrize("tile", ["224", "2562"])
+@pytest.mark.parametrize("tile", ["224", "2562", "64128"])
 def test_big_igemm_tiles_are_bit_identical_to_the_default(tile):
     """The 224x256 and 256x256 workgroup tiles are picked by a round-count model that only fires at full-size layers
     (and in tests/test_gpu_model.py's config-2 case); YFS_IGEMM_TILE forces one, read once per process, so a child

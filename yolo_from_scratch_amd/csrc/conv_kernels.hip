@@ -416,13 +416,14 @@ int launch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
 // the 192-channel outputs (stem + pool 584 vs 571 us, feat.2 dgrad 759 vs 738 us: no gain), a 3-deep ring for grids of
 // at most one workgroup per CU (feat.25-27, 200 tiles: 101 vs 96 us — a lone workgroup is not latency-bound either: its
 // 32 KiB per K-step at ~31 B/clk is 1060 of the 1390 cycles a step takes, the same per-CU staging limit as with two).
-// 128x192 serves the 192-channel outputs (pixel tile read once instead of three times with 128x64).  YFS_IGEMM_TILE=128|256|2562|224 forces a variant for benchmarking.
+// 128x192 serves the 192-channel outputs (pixel tile read once instead of three times with 128x64).  YFS_IGEMM_TILE=128|256|2562|224|64128 forces a variant for benchmarking.
 template <int EPI, bool SUB>
 int dispatch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
     static const int force = [] { const char* e = getenv("YFS_IGEMM_TILE"); return e ? atoi(e) : 0; }();
     if (g.NOUT % 192 == 0 && g.NOUT % 128 != 0 && force != 64) return launch_igemm<128, 192, 2, 2, 2, EPI, SUB>(g, s, name);
     if (g.NOUT % 128 != 0) return launch_igemm<128, 64, 2, 2, 2, EPI, SUB>(g, s, name);
     if (force == 256) return launch_igemm<256, 128, 4, 2, 3, EPI, SUB>(g, s, name);
+    if (force == 64128) return launch_igemm<64, 128, 2, 2, 2, EPI, SUB>(g, s, name);
     bool big = force == 2562 || force == 224, rows224 = force == 224;
     if (force == 0 && !SUB) {
         // rounds x time per round: 128x128 runs 512 tiles per round (2 per CU) in 2u, 256x256 runs 256 tiles per
@@ -439,6 +440,10 @@ int dispatch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
     }
     if (big && g.NOUT % 256 == 0)
         return rows224 ? launch_igemm<224, 256, 2, 4, 2, EPI, SUB>(g, s, name) : launch_igemm<256, 256, 2, 4, 2, EPI, SUB>(g, s, name);
+    // fewer 128x128 tiles than CUs (feat.25-27: 200 tiles): 64-row tiles put a workgroup on every CU (392 tiles; M = 49 * 64
+    // exactly): 96 -> 87 us per launch.  Not for the strided dgrad (slower there) nor for larger grids (L9/L17/L20: slower).
+    if (force == 0 && !SUB && yfs_cdiv(g.M, 128) * (g.NOUT / 128) <= 256 && yfs_cdiv(g.M, 64) * (g.NOUT / 128) > 256)
+        return launch_igemm<64, 128, 2, 2, 2, EPI, SUB>(g, s, name);
     return launch_igemm<128, 128, 2, 2, 2, EPI, SUB>(g, s, name);
 }
 
