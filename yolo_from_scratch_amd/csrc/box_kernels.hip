@@ -611,6 +611,23 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
     }
     // slot of the q-th box in class-major order
     auto member = [&](int q) -> int { return onesort ? (int)cslot[q] : (int)(key[q] & kSlotMask); };
+    {   // boxes into class-major order, in place through registers: phase C then reads cbox[q] with no indirection (one
+        // dependent LDS read less per pair, and the next pair's address is known early enough to prefetch)
+        constexpr int kMaxQ = (YFS_NMS_MAX_BOXES + kThreads - 1) / kThreads;
+        float4 tmp[kMaxQ];
+#pragma unroll
+        for (int r = 0; r < kMaxQ; ++r) {
+            const int q = tid + r * kThreads;
+            if (q < K) tmp[r] = cbox[member(q)];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kMaxQ; ++r) {
+            const int q = tid + r * kThreads;
+            if (q < K) cbox[q] = tmp[r];
+        }
+        // (visible to phase C through the barrier that follows the pair-count scan)
+    }
 
     // ---- C: greedy suppression per class segment ----
     // The textbook loop (for every kept box, test all later boxes) is one serial chain per segment and costs the same
@@ -671,13 +688,15 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
             while ((j + 1) * j / 2 <= r) ++j;
             int i = r - j * (j - 1) / 2;               // 0 <= i < j < len
             int p0 = seg_start(lo), len = seg_length(lo);
-            float4 bq = cbox[member(p0 + j)];
+            float4 bq = cbox[p0 + j];
+            float4 a = cbox[p0 + i];
             unsigned long long bits = 0ull;          // overlaps found for the current j
             for (;;) {
-                const float4 a = cbox[member(p0 + i)];
+                const float4 an = cbox[p0 + i + 1];  // next pair of this row (i + 1 <= j: in range), lands during the IoU
                 const float v = nms_pair_iou(a, bq);
                 if (v > g.iou_thr) bits |= 1ull << i;
                 const bool last = ++q == qend;
+                a = an;
                 if (++i == j || last) {              // leaving this j: publish its bits (other threads may hold part of it)
                     if (bits) atomicOr(&over[p0 + j], bits);
                     bits = 0ull;
@@ -688,7 +707,8 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
                         p0 = seg_start(lo);
                         j = 1;
                     }
-                    bq = cbox[member(p0 + j)];
+                    bq = cbox[p0 + j];
+                    a = cbox[p0];
                 }
             }
         }
@@ -721,13 +741,12 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
                 const unsigned hi32 = (unsigned)__shfl((int)(unsigned)(rem >> 32), own, 64);
                 const unsigned long long w = ((unsigned long long)hi32 << 32) | lo32;
                 if ((w >> ti) & 1ull) continue;
-                const int si = member(p0 + i);
                 if (lane == 0) kflag[p0 + i] = 1;
-                const float4 pb = cbox[si];
+                const float4 pb = cbox[p0 + i];
                 for (int t = ti; t < T; ++t) {
                     const int j = lane + 64 * t;
                     if (j > i && j < len) {
-                        const float4 q = cbox[member(p0 + j)];
+                        const float4 q = cbox[p0 + j];
                         const float v = yfs_iou_corners(pb.x, pb.y, pb.z, pb.w, q.x, q.y, q.z, q.w);
                         if (v > g.iou_thr) rem |= 1ull << t;
                     }
