@@ -395,7 +395,7 @@ __device__ long long yfs_nms_dbg[2][16];
 template <bool FUSED>
 __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ int wcnt[2][kThreads / 64];
+    __shared__ int wcnt[(YFS_NMS_MAX_BOXES + kThreads - 1) / kThreads][kThreads / 64];   // [round or parity][wave]
     __shared__ int ctl[4];
     __shared__ int cstart_s[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -471,24 +471,48 @@ __global__ void __launch_bounds__(kThreads) nms_kernel(NmsArgs g) {
             __syncthreads();   // everyone is done with rawlds before the next chunk lands in it
         }
     } else {
-        for (int i0 = 0; i0 < A; i0 += kThreads) {
-            const int i = i0 + tid;
-            bool pass = false;
-            float4 corners = make_float4(0.f, 0.f, 0.f, 0.f);
-            float sc = 0.f;
-            int cl = 0;
-            if (i < A) {
-                const int64_t o = n * A + i;
-                sc = g.score_in[o];
-                pass = sc >= g.score_thr;
-                if (pass) {
-                    const float4 v = g.boxes_in[o];
-                    corners = make_float4(v.x - 0.5f * v.z, v.y - 0.5f * v.w, v.x + 0.5f * v.z, v.y + 0.5f * v.w);
-                    cl = g.cls_in[o];
-                }
-            }
-            compact(pass, i, corners, sc, cl);
+        // all rounds of 256 boxes at once: scores loaded together, one ballot per round, ONE barrier for the wave counts
+        // of every round (instead of load -> ballot -> barrier per round), then the boxes and classes of the passing
+        // candidates are fetched together and written to their slots
+        constexpr int kMaxA = (YFS_NMS_MAX_BOXES + kThreads - 1) / kThreads;
+        float scr[kMaxA];
+        unsigned long long bal[kMaxA];
+#pragma unroll
+        for (int r = 0; r < kMaxA; ++r) {
+            const int i = r * kThreads + tid;
+            scr[r] = i < A ? g.score_in[n * A + i] : 0.0f;
         }
+#pragma unroll
+        for (int r = 0; r < kMaxA; ++r) {
+            const int i = r * kThreads + tid;
+            bal[r] = __ballot(i < A && scr[r] >= g.score_thr);
+            if (lane == 0) wcnt[r][wave] = __builtin_popcountll(bal[r]);
+        }
+        __syncthreads();
+        int off = 0;
+#pragma unroll
+        for (int r = 0; r < kMaxA; ++r) {
+            if (r * kThreads >= A) break;            // block-uniform
+            int mine = off;
+#pragma unroll
+            for (int w = 0; w < kThreads / 64; ++w) {
+                const int cw = wcnt[r][w];
+                mine += w < wave ? cw : 0;
+                off += cw;
+            }
+            if ((bal[r] >> lane) & 1ull) {
+                const int i = r * kThreads + tid;
+                const int64_t o = n * A + i;
+                const float4 v = g.boxes_in[o];
+                const int cl = g.cls_in[o];
+                const int slot = mine + __builtin_popcountll(bal[r] & ((1ull << lane) - 1ull));
+                cbox[slot] = make_float4(v.x - 0.5f * v.z, v.y - 0.5f * v.w, v.x + 0.5f * v.z, v.y + 0.5f * v.w);
+                cidx[slot] = i | (int)(((unsigned)cl & 0x1FFFFFu) << kSlotBits);   // [class:21 | box index:11]
+                key[slot] = make_key(cl, scr[r], slot);
+                maxcls = ((unsigned)cl & 0x1FFFFFu) > (unsigned)maxcls ? (int)((unsigned)cl & 0x1FFFFFu) : maxcls;
+            }
+        }
+        K = off;
         __syncthreads();
     }
 
