@@ -32,7 +32,6 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // Raw buffer descriptor over a whole tensor: loads whose byte offset is >= num_records return zeros in
 // hardware, which is how conv padding, tile tails and strided-dgrad holes are produced without branches
 // (a predicated global_load forces the compiler to wait for it right away; these stay in flight).
-constexpr unsigned kOOB = 0xFFFFFFFFu;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
@@ -190,18 +189,30 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) igemm_kernel(IgemmArgs g) {
     int kh = kh0, kw = kw0, cc = 0;   // position of the NEXT tile to stage
     typedef __attribute__((address_space(3))) void* lds_ptr;
 
+    // Source offsets of this thread's rows for the current tap; recomputed (bounds test included) only when the tap
+    // changes, i.e. once per C/64 K-steps: the steps in between just add 128 bytes.  Rows outside the image keep a
+    // sentinel that stays beyond the descriptor's range for any channel offset (tensors are < 0xFFF00000 bytes).
+    unsigned xoff[RA];
+    constexpr unsigned kOutside = 0xFFF00000u;
     auto stage_tile = [&](int it, int buf) {
         unsigned char* base = smem + buf * TILE_BYTES;
-        const int dh = SUB ? (ph - g.pad + kh) / g.sub_s : kh, dw = SUB ? (pw - g.pad + kw) / g.sub_s : kw;
-        const unsigned tapoff = (unsigned)(((dh * g.W + dw) * g.PS + cc * BK) * 2);
+        if (cc == 0) {   // block-uniform
+            const int dh = SUB ? (ph - g.pad + kh) / g.sub_s : kh, dw = SUB ? (pw - g.pad + kw) / g.sub_s : kw;
+            const unsigned tapoff = (unsigned)(((dh * g.W + dw) * g.PS) * 2);
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                const int sh = bh[i] + dh, sw = bw[i] + dw;
+                const bool ok = (unsigned)sh < (unsigned)g.H && (unsigned)sw < (unsigned)g.W;
+                xoff[i] = ok ? rowbyte[i] + tapoff : kOutside;
+            }
+        }
+        const unsigned cco = (unsigned)(cc * (BK * 2));
         const unsigned wk = SUB ? (unsigned)(((kh * g.KW + kw) * g.C + cc * BK) * 2) : (unsigned)it * (BK * 2);
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             if (RAGGED_A && (wave_u * RA + i) * 8 >= BM) continue;   // wave-uniform: no row group here
-            const int sh = bh[i] + dh, sw = bw[i] + dw;
-            const bool ok = (unsigned)sh < (unsigned)g.H && (unsigned)sw < (unsigned)g.W;
-            const unsigned off = rowbyte[i] + tapoff;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(base + (wave_u * RA + i) * 1024), 16, ok ? off : kOOB, 0, 0, 0);
+            const unsigned off = xoff[i] + cco;   // (a typed local: expressions passed straight to the builtin drop the kernel)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(base + (wave_u * RA + i) * 1024), 16, off, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
