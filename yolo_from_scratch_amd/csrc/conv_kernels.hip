@@ -427,6 +427,8 @@ int launch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
 // the 192-channel outputs (stem + pool 584 vs 571 us, feat.2 dgrad 759 vs 738 us: no gain), a 3-deep ring for grids of
 // at most one workgroup per CU (feat.25-27, 200 tiles: 101 vs 96 us — a lone workgroup is not latency-bound either: its
 // 32 KiB per K-step at ~31 B/clk is 1060 of the 1390 cycles a step takes, the same per-CU staging limit as with two).
+// First fragment reads of a K-step issued BEFORE the next tile's global -> LDS loads (so the matrix pipe starts one LDS
+// latency earlier after the barrier): 12.70 -> 12.88 ms per step — the loads landing that much later costs more.
 // A weight-major tile order (an XCD's run of tiles shares weight tiles instead of pixel tiles) for the layers whose weights
 // outweigh their activations (feat.21-27): 12.85 -> 12.88 ms per step, everywhere: 12.97 (rejected).
 // 128x192 serves the 192-channel outputs (pixel tile read once instead of three times with 128x64).  YFS_IGEMM_TILE=128|256|2562|224|64128 forces a variant for benchmarking.
