@@ -99,6 +99,16 @@ size_t yfs_yolov1_loss_workspace_bytes(int64_t N, int S);
 int yfs_yolov1_loss_fwd_bwd_f32(const float *pred, const float *target, int64_t N, int S, int B, int C,
                                 float l_coord, float l_noobj, float *loss_out, float *grad, void *workspace,
                                 size_t workspace_bytes, void *stream);
+/* The same loss for callers that cannot allocate device memory.  No counterpart in the reference: it exists
+ * for code under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same arguments and
+ * results (bit for bit) as yfs_yolov1_loss_fwd_bwd_f32 without the workspace: the per-block partial sums go to a
+ * 1 MiB array built into the library (one copy per GPU, resolved at the first call on each device), so
+ * N*S*S <= yfs_yolov1_loss_noalloc_max_cells() = 16,777,216 grid cells (YFS_ERR_UNSUPPORTED beyond).  Calls no
+ * hipMalloc / hipFree.  All calls on one GPU share that array: calls that overlap on one GPU (different streams
+ * or threads) race; serialise them or use the workspace form. */
+int64_t yfs_yolov1_loss_noalloc_max_cells(void);
+int yfs_yolov1_loss_noalloc_f32(const float *pred, const float *target, int64_t N, int S, int B, int C,
+                                float l_coord, float l_noobj, float *loss_out, float *grad, void *stream);
 /* nn.MSELoss()  yolo_toy_regressor_torch.py:377 (mean over all n elements) + gradient. */
 size_t yfs_mse_workspace_bytes(int64_t n);
 int yfs_mse_fwd_bwd_f32(const float *pred, const float *target, int64_t n, float *loss_out, float *grad,

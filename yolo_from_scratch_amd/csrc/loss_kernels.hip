@@ -3,6 +3,13 @@
 // The loss slots in where the reference calls loss_fn(preds, yb) (yolo_toy_regressor_torch.py:329).
 // Built with -ffp-contract=off so the responsible-box choice (argmax IoU) matches the CPU oracle.
 #include "yfs_common.h"
+#include <mutex>
+
+// Scratch of yfs_yolov1_loss_noalloc_f32 (the entry point for callers that cannot allocate): the per-block partial
+// sums of the four loss terms.  One copy per GPU the library runs on, held until the process ends.  Host code never
+// uses this name as an address: noalloc_scratch() resolves it per device with hipGetSymbolAddress.
+constexpr int64_t kNoAllocMaxBlocks = 65536;                         // x 256 cells = 16,777,216 grid cells
+static __device__ __align__(256) float scratch[kNoAllocMaxBlocks * 4];   // 1 MiB
 
 namespace {
 
@@ -293,6 +300,49 @@ YFS_API int yfs_yolov1_loss_fwd_bwd_f32(const float* pred, const float* target, 
     loss_finalize_kernel<<<1, kThreads, 0, s>>>((const float*)workspace, nblk, 1.0f / (float)N, loss_out);
     YFS_CHECK_LAUNCH("loss_finalize_kernel");
     return YFS_OK;
+}
+
+// ---- the same loss for callers that cannot allocate ------------------------------------------------------------------
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+float* g_scratch_ptr[kMaxDevices] = {};   // device address of `scratch` on each GPU (every GPU holds its own copy)
+
+// Device address of this GPU's copy of `scratch`; resolved once per device, with that device current.
+int noalloc_scratch(float** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    YFS_REQUIRE(e == hipSuccess && dev >= 0 && dev < kMaxDevices, YFS_ERR_LAUNCH,
+                "yfs_yolov1_loss_noalloc_f32: hipGetDevice failed or device index %d out of range", dev);
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        YFS_REQUIRE(e == hipSuccess && p, YFS_ERR_LAUNCH, "yfs_yolov1_loss_noalloc_f32: hipGetSymbolAddress failed: %s",
+                    hipGetErrorString(e));
+        g_scratch_ptr[dev] = (float*)p;
+    }
+    *out = g_scratch_ptr[dev];
+    return YFS_OK;
+}
+}  // namespace
+
+YFS_API int64_t yfs_yolov1_loss_noalloc_max_cells(void) { return kNoAllocMaxBlocks * kThreads; }
+
+YFS_API int yfs_yolov1_loss_noalloc_f32(const float* pred, const float* target, int64_t N, int S, int B, int C, float l_coord,
+                                        float l_noobj, float* loss_out, float* grad, void* stream) {
+    YFS_REQUIRE(N > 0 && S > 0, YFS_ERR_INVALID_ARG, "yfs_yolov1_loss_noalloc_f32: bad shape N=%lld S=%d", (long long)N, S);
+    YFS_REQUIRE(N * S * S <= kNoAllocMaxBlocks * kThreads, YFS_ERR_UNSUPPORTED,
+                "yfs_yolov1_loss_noalloc_f32: N*S*S=%lld grid cells exceed the built-in scratch (%lld cells); use "
+                "yfs_yolov1_loss_fwd_bwd_f32 with a caller-owned workspace",
+                (long long)(N * S * S), (long long)(kNoAllocMaxBlocks * kThreads));
+    float* ws = nullptr;
+    int rc = noalloc_scratch(&ws);
+    if (rc) return rc;
+    // Every partial the finalize kernel reads (blocks 0 .. nblk-1) is written by this call's loss kernel first, so
+    // nothing in the scratch has to start at zero; what a previous call left behind is never read.
+    return yfs_yolov1_loss_fwd_bwd_f32(pred, target, N, S, B, C, l_coord, l_noobj, loss_out, grad, ws,
+                                       (size_t)yfs_cdiv(N * S * S, kThreads) * 4 * sizeof(float), stream);
 }
 
 YFS_API size_t yfs_mse_workspace_bytes(int64_t n) { return n > 0 ? (size_t)mse_blocks(n) * sizeof(float) : 0; }
