@@ -15,7 +15,8 @@
  *   - `stream` is a hipStream_t passed as void*.  Kernels are enqueued on it; nothing synchronises.
  *   - return value: 0 = success, negative = yfs_status.  yfs_last_error() gives the thread-local
  *     message of the last failure on the calling thread.
- *   - no global mutable state: calls from several host threads on distinct streams are safe.
+ *   - no global mutable state (calls from several host threads on distinct streams are safe) with two documented
+ *     exceptions: the tuning knobs below (measurement aids) and the built-in scratch of yfs_yolov1_loss_noalloc_f32.
  */
 #ifndef YFS_H
 #define YFS_H
@@ -38,6 +39,20 @@ typedef enum {
 int yfs_version(void);
 /* copies the calling thread's last error message (NUL-terminated, truncated to n); returns its length */
 int yfs_last_error(char *buf, size_t n);
+
+/* Tuning knobs: measurement aids for tools/conv_bench.py, tools/probes and the forced-tile tests.  Process-wide
+ * integers, 0 = the library's own choice (the default and the only supported production setting).  Their initial
+ * values come from the environment variables of the same name (YFS_IGEMM_TILE, YFS_WGRAD_TILE, YFS_WGRAD_SPLITS,
+ * YFS_NMS_FUSED), read once at the first use of any knob.  Changing a knob while another thread launches kernels
+ * affects that thread's tile choice, never its results beyond fp32 summation order.
+ *   YFS_KNOB_IGEMM_TILE    forward/dgrad workgroup tile: 128 | 64128 | 224 | 2562 | 256 | 8 (256x256, 8-phase schedule)
+ *   YFS_KNOB_WGRAD_TILE    weight-gradient tile: 64 | 12864 | 8 (256x256, 8-phase schedule)
+ *   YFS_KNOB_WGRAD_SPLITS  split-K factor of the weight gradient (> 0 forces it)
+ *   YFS_KNOB_NMS_FUSED     1: yfs_decode_nms_f32 decodes inside the NMS kernel (one launch) */
+typedef enum { YFS_KNOB_IGEMM_TILE = 0, YFS_KNOB_WGRAD_TILE = 1, YFS_KNOB_WGRAD_SPLITS = 2, YFS_KNOB_NMS_FUSED = 3,
+               YFS_KNOB_COUNT = 4 } yfs_knob_id;
+int yfs_set_knob(int knob, int value);
+int yfs_get_knob(int knob);
 
 /* ---- kernel set 3: box math, decode, NMS ---------------------------------------------------- */
 
@@ -119,7 +134,8 @@ int yfs_mse_fwd_bwd_f32(const float *pred, const float *target, int64_t n, float
  * bf16 NHWC activations, bf16 weights [Cout,K,K,Cin], fp32 accumulate on MFMA. */
 
 /* y = leaky(conv(x, w) + bias).  x [N,H,W,Cin] bf16, w [Cout,K,K,Cin] bf16, bias [Cout] fp32,
- * y [N,Ho,Wo,Cout] bf16.  Cin % 8 == 0 (conv1's Cin=3 goes through yfs_im2col_bf16 first). */
+ * y [N,Ho,Wo,Cout] bf16.  Cin % 64 == 0 and Cout % 64 == 0 (conv1's Cin=3 goes through the stem entry points
+ * below, or through yfs_im2col_bf16 first). */
 int yfs_conv2d_fwd_bf16(const void *x, const void *w, const float *bias, void *y, int64_t N, int H, int W,
                         int Cin, int Cout, int K, int stride, float slope, void *stream);
 /* dx = conv_transpose(dz, w) [* leaky'(x_act) when x_act != NULL].  dz [N,Ho,Wo,Cout] bf16,

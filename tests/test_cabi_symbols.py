@@ -27,7 +27,7 @@ def test_header_symbols_exported():
 def test_version_and_error_channel():
     import yolo_from_scratch_amd as y
     lib = y.lib()
-    assert lib.yfs_version() >= 100
+    assert lib.yfs_version() >= 200
     # argument validation happens on the host before any launch: safe without a GPU
     rc = lib.yfs_decode_head_f32(None, ctypes.c_int64(4), ctypes.c_float(1), ctypes.c_float(1), None, None)
     assert rc == -1

@@ -235,45 +235,71 @@ def test_stem_wgrad_from_pooled_side(n, hw, cout, leaky):
     assert float((db - db_ref).abs().max()) <= 1e-5 * float(db_ref.abs().max()) + 1e-6
 
 
-@pytest.mark.parametrize("tile", ["224", "2562", "64128"])
+def _forced_tile_outputs():
+    outs = []
+    for n, cin, cout, k, hw in [(3, 64, 256, 3, 15), (2, 128, 512, 1, 14), (1, 64, 256, 3, 30), (2, 192, 256, 3, 20)]:
+        g = torch.Generator().manual_seed(cin + hw)
+        x = co.nhwc((torch.rand(n, cin, hw, hw, generator=g) - 0.3).to(DEV), torch.bfloat16)
+        w = co.nhwc(((torch.rand(cout, cin, k, k, generator=g) * 2 - 1) / (cin * k * k) ** 0.5).to(DEV))
+        b = ((torch.rand(cout, generator=g) * 2 - 1) * 0.1).to(DEV)
+        w16, wt16 = co.weight_prep(w)
+        y = co.conv_fwd(x, w16, b, 1)
+        outs.append(y)
+        if hw % 2 == 0:
+            outs.extend(co.conv_fwd_pool(x, w16, b, 1))
+        act = co.nhwc(torch.randn(n, cout, hw, hw, generator=g).to(DEV), torch.bfloat16)
+        w2 = co.nhwc(((torch.rand(cout, cout, k, k, generator=g) * 2 - 1) / (cout * k * k) ** 0.5).to(DEV))
+        outs.append(co.conv_dgrad(y, co.weight_prep(w2)[1], (hw, hw), 1, x_act=act))
+        outs.append(co.conv_dgrad(y, co.weight_prep(w2)[1], (hw, hw), 1))
+    return [t.float().cpu() for t in outs]
+
+
+@pytest.mark.parametrize("tile", [224, 2562, 64128, 8, 87])
 def test_big_igemm_tiles_are_bit_identical_to_the_default(tile):
-    """The 224x256 and 256x256 workgroup tiles are picked by a round-count model that only fires at full-size layers
-    (and in tests/test_gpu_model.py's config-2 case); YFS_IGEMM_TILE forces one, read once per process, so a child
-    process runs forward, pool-fused forward and masked dgrad on ragged shapes (M not a multiple of the tile) with the
-    forced tile.  Every output element accumulates the same K-steps in the same order whatever the tile, so the results
-    must equal the default 128x128 tile's bit for bit."""
-    import subprocess
-    import sys
-    import tempfile
-    code = (
-        "import sys, numpy as np, torch\n"
-        "from yolo_from_scratch_amd import conv_ops as co\n"
-        "outs = []\n"
-        "for n, cin, cout, k, hw in [(3, 64, 256, 3, 15), (2, 128, 512, 1, 14), (1, 64, 256, 3, 30)]:\n"
-        "    g = torch.Generator().manual_seed(cin + hw)\n"
-        "    x = co.nhwc((torch.rand(n, cin, hw, hw, generator=g) - 0.3).cuda(), torch.bfloat16)\n"
-        "    w = co.nhwc(((torch.rand(cout, cin, k, k, generator=g) * 2 - 1) / (cin * k * k) ** 0.5).cuda())\n"
-        "    b = ((torch.rand(cout, generator=g) * 2 - 1) * 0.1).cuda()\n"
-        "    w16, wt16 = co.weight_prep(w)\n"
-        "    y = co.conv_fwd(x, w16, b, 1)\n"
-        "    outs.append(y)\n"
-        "    if hw % 2 == 0:\n"
-        "        outs.extend(co.conv_fwd_pool(x, w16, b, 1))\n"
-        "    act = co.nhwc(torch.randn(n, cout, hw, hw, generator=g).cuda(), torch.bfloat16)\n"
-        "    w2 = co.nhwc(((torch.rand(cout, cout, k, k, generator=g) * 2 - 1) / (cout * k * k) ** 0.5).cuda())\n"
-        "    outs.append(co.conv_dgrad(y, co.weight_prep(w2)[1], (hw, hw), 1, x_act=act))\n"
-        "np.savez(sys.argv[1], *[t.float().cpu().numpy() for t in outs])\n")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with tempfile.TemporaryDirectory() as d:
-        res = {}
-        for name, force in (("default", None), ("forced", tile)):
-            env = dict(os.environ, PYTHONPATH=root)
-            env.pop("YFS_IGEMM_TILE", None)
-            if force:
-                env["YFS_IGEMM_TILE"] = force
-            path = os.path.join(d, name + ".npz")
-            subprocess.run([sys.executable, "-c", code, path], check=True, env=env, cwd=root, timeout=110)
-            res[name] = np.load(path)
-        assert len(res["default"].files) == 10
-        for key in res["default"].files:
-            np.testing.assert_array_equal(res["forced"][key], res["default"][key])
+    """The 224x256 / 256x256 workgroup tiles and the 8-phase 256x256 kernel are picked by a cost model that only fires
+    at full-size layers (and in tests/test_gpu_model.py's config-2 case); the YFS_KNOB_IGEMM_TILE tuning knob forces
+    one, so forward, pool-fused forward, masked and plain dgrad run on ragged shapes (M not a multiple of the tile, odd
+    and even K-step counts) with the forced tile.  Every output element accumulates the same K-steps in the same order
+    whatever the tile, so the results must equal the default tile's bit for bit."""
+    from yolo_from_scratch_amd import _lib as L
+    assert L.get_knob("igemm_tile") == 0
+    ref = _forced_tile_outputs()
+    L.set_knob("igemm_tile", tile)
+    try:
+        got = _forced_tile_outputs()
+    finally:
+        L.set_knob("igemm_tile", 0)
+    assert len(ref) == 18
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n,cin,cout,k,s,hw", [(2, 256, 256, 3, 1, 9), (3, 192, 256, 3, 1, 12), (1, 512, 512, 1, 1, 14),
+                                               (2, 256, 512, 3, 2, 14), (5, 192, 256, 3, 1, 20), (2, 512, 256, 3, 1, 6)])
+def test_wgrad_8phase_kernel_matches_default(n, cin, cout, k, s, hw):
+    """wgrad8_kernel (256-wide tiles, forced through the YFS_KNOB_WGRAD_TILE tuning knob; split-K factors 1 and 3, ragged
+    pixel counts, odd and even K-step counts, stride 2, the 192-channel ci tile) against the default weight-gradient
+    kernel: same bf16 operands, fp32 accumulation, only the summation order over pixels differs."""
+    from yolo_from_scratch_amd import _lib as L
+    g = torch.Generator().manual_seed(n * 1000 + cin + cout + hw)
+    x = co.nhwc((torch.rand(n, cin, hw, hw, generator=g) - 0.4).to(DEV), torch.bfloat16)
+    oh, ow = co.out_hw(hw, hw, k, s)
+    dz = co.nhwc(torch.randn(n, cout, oh, ow, generator=g).to(DEV), torch.bfloat16)
+    dw_ref, db_ref = co.conv_wgrad(x, dz, k, s)
+    for splits in (1, 3):
+        L.set_knob("wgrad_tile", 8)
+        L.set_knob("wgrad_splits", splits)
+        try:
+            dw, db = co.conv_wgrad(x, dz, k, s)
+            dw2, db2 = co.conv_wgrad(x, dz, k, s, dw=dw.clone(), db=db.clone())      # accumulate path
+            dw3, _ = co.conv_wgrad(x, dz, k, s, want_db=False)
+        finally:
+            L.set_knob("wgrad_tile", 0)
+            L.set_knob("wgrad_splits", 0)
+        tol = 2e-5 * float(dw_ref.abs().max()) + 1e-6
+        assert float((dw - dw_ref).abs().max()) <= tol, f"splits={splits}"
+        assert float((dw3 - dw_ref).abs().max()) <= tol
+        assert float((dw2 - 2 * dw_ref).abs().max()) <= 2 * tol
+        tolb = 2e-5 * float(db_ref.abs().max()) + 1e-6
+        assert float((db - db_ref).abs().max()) <= tolb
+        assert float((db2 - 2 * db_ref).abs().max()) <= 2 * tolb

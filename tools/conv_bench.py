@@ -26,7 +26,14 @@ def main():
     ap.add_argument("--layers", default=",".join(str(k) for k in LAYERS))
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--igemm-tile", type=int, default=0, help="YFS_KNOB_IGEMM_TILE (0 = library's choice)")
+    ap.add_argument("--wgrad-tile", type=int, default=0, help="YFS_KNOB_WGRAD_TILE")
+    ap.add_argument("--wgrad-splits", type=int, default=0, help="YFS_KNOB_WGRAD_SPLITS")
     a = ap.parse_args()
+    from yolo_from_scratch_amd import _lib as L
+    L.set_knob("igemm_tile", a.igemm_tile)
+    L.set_knob("wgrad_tile", a.wgrad_tile)
+    L.set_knob("wgrad_splits", a.wgrad_splits)
     dev = "cuda:0"
     tot = {op: 0.0 for op in a.ops.split(",")}
     for li in [int(v) for v in a.layers.split(",")]:

@@ -30,6 +30,18 @@ def lib():
     return _lib
 
 
+KNOBS = {"igemm_tile": 0, "wgrad_tile": 1, "wgrad_splits": 2, "nms_fused": 3}     # include/yfs.h: yfs_knob_id
+
+
+def set_knob(name, value):
+    """Measurement aid (include/yfs.h, tuning knobs): force a kernel variant; 0 restores the library's own choice."""
+    check(lib().yfs_set_knob(ctypes.c_int(KNOBS[name]), ctypes.c_int(int(value))), "yfs_set_knob")
+
+
+def get_knob(name):
+    return lib().yfs_get_knob(ctypes.c_int(KNOBS[name]))
+
+
 def last_error():
     buf = ctypes.create_string_buffer(512)
     lib().yfs_last_error(buf, ctypes.c_size_t(512))

@@ -978,7 +978,7 @@ YFS_API int yfs_decode_nms_f32(const float* raw, int64_t N, int S, int A, int C,
     // on the image's critical path (7 chunks = 36 % of the kernel).  Decoded boxes / scores / classes are outputs of this
     // entry point anyway, so the only extra traffic is the NMS kernel reading the 3.4 KB of scores per image back
     // (+ the boxes that pass).  Measured on config 4: 0.102 -> two launches; YFS_NMS_FUSED=1 keeps the one-launch kernel.
-    static const bool fused = [] { const char* e = getenv("YFS_NMS_FUSED"); return e && atoi(e) != 0; }();
+    const bool fused = yfs_knob(YFS_KNOB_NMS_FUSED) != 0;
     if (!fused) {
         int rc = yfs_decode_grid_f32(raw, N, S, A, C, anchors, boxes, score, cls, nullptr, stream);
         if (rc) return rc;

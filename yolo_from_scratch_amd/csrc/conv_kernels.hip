@@ -412,6 +412,325 @@ int launch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
     return YFS_OK;
 }
 
+// ---- 256 x 256 x 64 tile, 8 waves, staggered wave groups ("8-phase" schedule) -----------------------------------
+// The 2-stage loops above pay one vmcnt(0) + barrier hand-off per K-step with every wave in the same state: all
+// loading, then all multiplying.  Here the tile is cut into four 16 KiB half-tiles per K-step (pixel rows 0-127 /
+// 128-255 = P0 / P1, weight rows W0 / W1; two LDS buffers of four half-tiles = 128 KiB), a K-step into four phases,
+// one 64 x 32 output quadrant of every wave each (wave = 2 x 2 quadrants: 128 pixels x 64 channels, 128 accumulator
+// registers), and the two wave rows run one barrier apart: while waves 0-3 multiply (16 MFMAs between two barriers),
+// waves 4-7 — their partners on the same four SIMDs — read fragments and issue the next LDS-DMA, and vice versa, so
+// the matrix pipe of every SIMD always has one wave feeding it.
+//   phase 1: read W0, P0 fragments | stage P1 of tile t+1 | MFMA quadrant (P0, W0)
+//   phase 2: read W1               | stage W0 of tile t+2 | MFMA (P0, W1)
+//   phase 3: read P1               | stage P0 of tile t+2 | MFMA (P1, W1)
+//   phase 4: (W0 stays in regs)    | stage W1 of tile t+2 | MFMA (P1, W0)   + the only vmcnt wait of the K-step
+// A half-tile is restaged as soon as its fragments are in registers (>= 2 phases after it was read; W0 one phase
+// after, which is why every wave retires its reads with lgkmcnt(0) BEFORE the phase's first barrier), i.e. the loads
+// run two K-steps ahead with two buffers.  vmcnt(6) in phase 4 leaves the three half-tiles issued in phases 2-4 in
+// flight (2 LDS-DMA instructions per wave and half-tile) and retires everything older = all of tile t+1, which is
+// first read two barriers later.  Barriers are raw s_barrier (a __syncthreads() would drain the DMA queue).
+constexpr int B8_HALF = 128 * 128;     // one half-tile: 128 rows x 128 B
+constexpr int B8_BUF = 4 * B8_HALF;    // [P0 | P1 | W0 | W1]
+constexpr int B8_LDS = 2 * B8_BUF;
+constexpr int B8_EPI_STRIDE = 256 * 4 + 16, B8_EPI_ROWS = 64;   // epilogue: four slabs of 64 rows through the ring
+
+// FP1 = pixel fragments per wave in the SECOND pixel half-tile: 4 -> 256-row tile, 3 -> 224-row tile (P1 holds 96 rows,
+// phases 3 and 4 run 12 MFMAs).  Every GEMM M of this network is 64 * (7 * 2^k)^2, so 224-row tiles have no ragged edge
+// and their counts (224, 448, 896, ...) fill 256 CUs to 87.5-100 % where 196 / 392 / 784 tiles of 256 rows fill 76.6 %.
+template <int EPI, int FP1>
+__global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
+    constexpr int BM = 128 + FP1 * 32, BN = 256, NT = 512;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int logical = xcd_remap(blockIdx.x, g.mtiles * g.ntiles);
+    const int nt = logical % g.ntiles, mt = logical / g.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int Mc = g.M, OHc = g.OH, OWc = g.OW;
+
+    // ---- staging coordinates: 4 pixel rows and 4 weight rows per thread (2 per half-tile) -----------------------------
+    const int chunk = (lane & 7) ^ (lane >> 3);   // source-side XOR swizzle (see igemm_kernel)
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.x, g.xbytes), rw = make_rsrc(g.w, g.wbytes);
+    int bh[4], bw[4];
+    unsigned rowbyte[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {   // j = half * 2 + i: tile row half*128 + wave*16 + i*8 + (lane >> 3)
+        const int hr = wave * 16 + (j & 1) * 8 + (lane >> 3);   // row inside the half-tile
+        const int m = m0 + (j >> 1) * 128 + hr;
+        if (m < Mc && (j < 2 || hr < FP1 * 32)) {
+            int n, oh, ow;
+            if (EPI == EPI_POOL) {   // window-major row order (see igemm_kernel)
+                const int q = m >> 2, sub = m & 3, PW = OWc >> 1, PHW = (OHc >> 1) * PW;
+                n = q / PHW;
+                const int r = q - n * PHW;
+                const int py = r / PW, px = r - py * PW;
+                oh = 2 * py + (sub >> 1);
+                ow = 2 * px + (sub & 1);
+            } else {
+                n = m / (OHc * OWc);
+                const int rem = m - n * (OHc * OWc);
+                oh = rem / OWc;
+                ow = rem - oh * OWc;
+            }
+            bh[j] = oh * g.s_mul - g.pad;
+            bw[j] = ow * g.s_mul - g.pad;
+            rowbyte[j] = (unsigned)(((long long)(n * g.H + bh[j]) * g.W + bw[j]) * g.PS * 2) + chunk * 16;
+        } else {
+            bh[j] = -(1 << 28);
+            bw[j] = -(1 << 28);
+            rowbyte[j] = 0;
+        }
+    }
+    const unsigned ktot = (unsigned)(g.KH * g.KW * g.C);
+    const unsigned wrow = (unsigned)(n0 + wave * 16 + (lane >> 3)) * ktot * 2 + chunk * 16;
+    const int cchunks = g.C / BK;
+    const int nit = g.KH * g.KW * cchunks;
+
+    // position of the tile the staging state describes: tile ts = (kh, kw, cc); xoff = this thread's source offsets
+    // for that tap (recomputed when the tap changes)
+    int kh = 0, kw = 0, cc = 0, ts = 0;
+    unsigned xoff[4];
+    constexpr unsigned kOutside = 0xFFF00000u;
+    auto tap_offsets = [&]() {
+        const unsigned tapoff = (unsigned)(((kh * g.W + kw) * g.PS) * 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int sh = bh[j] + kh, sw = bw[j] + kw;
+            const bool ok = (unsigned)sh < (unsigned)g.H && (unsigned)sw < (unsigned)g.W;
+            xoff[j] = ok ? rowbyte[j] + tapoff : kOutside;
+        }
+    };
+    auto advance = [&]() {
+        ++ts;
+        if (++cc == cchunks) {
+            cc = 0;
+            if (++kw >= g.KW) { kw = 0; ++kh; }
+            tap_offsets();
+        }
+    };
+    auto stage_P = [&](int h, int buf) {
+        const unsigned so = (unsigned)(cc * (BK * 2));   // wave-uniform part goes in the scalar offset
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned off = xoff[h * 2 + i];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(smem + buf * B8_BUF + h * B8_HALF + (wave * 2 + i) * 1024), 16,
+                                                     off, so, 0, 0);
+        }
+    };
+    auto stage_W = [&](int h, int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned so = ((unsigned)(h * 128 + i * 8) * ktot + (unsigned)ts * BK) * 2;
+            const unsigned off = wrow;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(smem + buf * B8_BUF + (2 + h) * B8_HALF + (wave * 2 + i) * 1024),
+                                                     16, off, so, 0, 0);
+        }
+    };
+
+    f32x4 acc[2][2][2][4];   // [pixel half][weight half][channel fragment][pixel fragment]
+#pragma unroll
+    for (int i = 0; i < 32; ++i) (&acc[0][0][0][0])[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fk = lane >> 4;
+    bf16x8 pf[4][2], w0f[2][2], w1f[2][2];
+    auto read_P = [&](const unsigned char* hb, auto nf_tag) {   // nf_tag: fragments per wave in this half (4 or FP1)
+        constexpr int NF = decltype(nf_tag)::value;
+#pragma unroll
+        for (int b = 0; b < NF; ++b)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                pf[b][ks] = *reinterpret_cast<const bf16x8*>(hb + swz(wm * (NF * 16) + b * 16 + frow, ks * 4 + fk));
+    };
+    auto read_W = [&](const unsigned char* hb, bf16x8 (&wf)[2][2]) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                wf[a][ks] = *reinterpret_cast<const bf16x8*>(hb + swz(wn * 32 + a * 16 + frow, ks * 4 + fk));
+    };
+    auto mfma16 = [&](f32x4 (&c)[2][4], const bf16x8 (&wf)[2][2], auto nf_tag) {
+        constexpr int NF = decltype(nf_tag)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < NF; ++b) c[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a][ks], pf[b][ks], c[a][b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto lgkm0 = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+    auto bar = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // prologue: tile 0 complete, W0 / P0 / W1 of tile 1 in flight (the steady state at the top of a K-step)
+    tap_offsets();
+    stage_W(0, 0); stage_P(0, 0); stage_W(1, 0); stage_P(1, 0);
+    if (nit > 1) {
+        advance();
+        stage_W(0, 1); stage_P(0, 1); stage_W(1, 1);
+        wait_vmcnt<6>();
+    } else {
+        wait_vmcnt<0>();
+    }
+    bar();
+    if (wm == 1) bar();   // waves 4-7 run one barrier behind waves 0-3 from here on
+
+    const std::integral_constant<int, 4> F4;
+    const std::integral_constant<int, FP1> F1;
+    auto tile = [&](int t, auto buf_tag) {
+        constexpr int BUF = decltype(buf_tag)::value;
+        const unsigned char* tb = smem + BUF * B8_BUF;
+        // phase 1
+        read_W(tb + 2 * B8_HALF, w0f);
+        read_P(tb, F4);
+        if (t + 1 < nit) stage_P(1, BUF ^ 1);
+        lgkm0();
+        bar();
+        mfma16(acc[0][0], w0f, F4);
+        bar();
+        // phase 2
+        read_W(tb + 3 * B8_HALF, w1f);
+        advance();
+        if (ts < nit) stage_W(0, BUF);
+        lgkm0();
+        bar();
+        mfma16(acc[0][1], w1f, F4);
+        bar();
+        // phase 3
+        read_P(tb + B8_HALF, F1);
+        if (ts < nit) stage_P(0, BUF);
+        lgkm0();
+        bar();
+        mfma16(acc[1][1], w1f, F1);
+        bar();
+        // phase 4
+        if (ts < nit) {
+            stage_W(1, BUF);
+            wait_vmcnt<6>();
+        } else {
+            wait_vmcnt<0>();
+        }
+        bar();
+        mfma16(acc[1][0], w0f, F1);
+        bar();
+    };
+    int t = 0;
+    for (; t + 1 < nit; t += 2) {
+        tile(t, std::integral_constant<int, 0>());
+        tile(t + 1, std::integral_constant<int, 1>());
+    }
+    if (t < nit) tile(t, std::integral_constant<int, 0>());
+    if (wm == 0) bar();   // catch up with waves 4-7: every wave is past its last fragment read after this
+
+    // ---- epilogue: four 64-row slabs of the fp32 tile through LDS, then coalesced 16 B stores (as igemm_kernel) ----
+    // acc[ph][wh][a][b][r] = out[pixel ph*128 + wm*NF*16 + b*16 + (lane&15)][chan wh*128 + wn*32 + a*16 + (lane>>4)*4 + r]
+    // with NF = 4 fragments per wave in the first pixel half and FP1 in the second; slab = one wave row of one half
+    constexpr int TPR = BN / 8, RPP = NT / TPR;
+    const int ec = (tid % TPR) * 8, er = tid / TPR;
+    float bv[8];
+    if (EPI == EPI_BIAS_LEAKY) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bv[j] = g.bias[n0 + ec + j];
+    }
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        constexpr int kNF[2] = {4, FP1};
+        const int NF = kNF[pass >> 1];
+        const int PR = NF * 16;                                       // rows of this slab
+        const int rbase = (pass >> 1) * 128 + (pass & 1) * PR;        // its first row in the tile
+        const int SWEEPS = PR / RPP;
+        if (wm == (pass & 1)) {
+#pragma unroll
+            for (int wh = 0; wh < 2; ++wh)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        if (b >= NF) continue;
+                        const int ch = wh * 128 + wn * 32 + a * 16 + fk * 4;
+                        *reinterpret_cast<f32x4*>(smem + (b * 16 + frow) * B8_EPI_STRIDE + ch * 4) = acc[pass >> 1][wh][a][b];
+                    }
+        }
+        __syncthreads();
+        if (EPI == EPI_POOL) {
+            // one item per thread: (window, 8 channels); see igemm_kernel for the pooling rule
+            const int w = tid / TPR, c8 = tid - w * TPR;
+            const int q = ((m0 + rbase) >> 2) + w;
+            if (w < PR / 4 && q * 4 < Mc) {
+                float bvp[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bvp[j] = g.bias[n0 + c8 * 8 + j];
+                bf16x8 best;
+                unsigned packed = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned char* rp = smem + (4 * w + k) * B8_EPI_STRIDE + c8 * 32;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(rp);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(rp + 16);
+                    const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float tv = v[j] + bvp[j];
+                        const bf16_t yv = (bf16_t)(tv > 0.0f ? tv : tv * g.slope);
+                        if (k == 0 || (float)yv > (float)best[j]) {
+                            best[j] = yv;
+                            packed = (packed & ~(3u << (2 * j))) | ((unsigned)k << (2 * j));
+                        }
+                    }
+                }
+                *reinterpret_cast<bf16x8*>(g.out + (long long)q * g.NOUT + n0 + c8 * 8) = best;
+                g.pool_idx[(long long)q * (g.NOUT / 8) + (n0 >> 3) + c8] = (unsigned short)packed;
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if (p >= SWEEPS) continue;
+                const int row = er + p * RPP;
+                const int m = m0 + rbase + row;
+                if (m >= Mc) continue;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(smem + row * B8_EPI_STRIDE + ec * 4);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(smem + row * B8_EPI_STRIDE + ec * 4 + 16);
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                const long long o = (long long)m * g.NOUT + n0 + ec;
+                if (EPI == EPI_BIAS_LEAKY) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float tv = v[j] + bv[j];
+                        v[j] = tv > 0.0f ? tv : tv * g.slope;
+                    }
+                } else if (EPI == EPI_MASK) {
+                    const bf16x8 av = *reinterpret_cast<const bf16x8*>(g.act + o);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = (float)av[j] > 0.0f ? v[j] : v[j] * g.slope;
+                }
+                bf16x8 ov;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ov[j] = (bf16_t)v[j];
+                *reinterpret_cast<bf16x8*>(g.out + o) = ov;
+            }
+        }
+        if (pass < 3) __syncthreads();
+    }
+}
+
+template <int EPI, int FP1>
+int launch_igemm8(IgemmArgs& g, hipStream_t s, const char* name) {
+    g.mtiles = (int)yfs_cdiv(g.M, 128 + FP1 * 32);
+    g.ntiles = g.NOUT / 256;
+    auto kern = igemm8_kernel<EPI, FP1>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, B8_LDS);
+    YFS_REQUIRE(e == hipSuccess, YFS_ERR_LAUNCH, "%s: cannot reserve %d bytes of LDS", name, B8_LDS);
+    kern<<<dim3((unsigned)(g.mtiles * g.ntiles)), dim3(512), B8_LDS, s>>>(g);
+    YFS_CHECK_LAUNCH(name);
+    return YFS_OK;
+}
+
 // Tile choice (measured on MI355X, batch 64, tools/conv_bench.py).  Default: 128x128 / 4 waves / 2-stage 64-deep
 // ring at two workgroups per CU (L7 ~1000, L18 ~1070 TFLOP/s).  Ablations show why it sits at ~40 % of the MFMA
 // peak: with the global->LDS staging removed the same loop runs at 1340-1560 TFLOP/s, with staging that fetches
@@ -431,14 +750,33 @@ int launch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
 // latency earlier after the barrier): 12.70 -> 12.88 ms per step — the loads landing that much later costs more.
 // A weight-major tile order (an XCD's run of tiles shares weight tiles instead of pixel tiles) for the layers whose weights
 // outweigh their activations (feat.21-27): 12.85 -> 12.88 ms per step, everywhere: 12.97 (rejected).
-// 128x192 serves the 192-channel outputs (pixel tile read once instead of three times with 128x64).  YFS_IGEMM_TILE=128|256|2562|224|64128 forces a variant for benchmarking.
+// 128x192 serves the 192-channel outputs (pixel tile read once instead of three times with 128x64).  The YFS_KNOB_IGEMM_TILE knob (128|256|2562|224|64128|8) forces a variant for benchmarking and tests.
 template <int EPI, bool SUB>
 int dispatch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
-    static const int force = [] { const char* e = getenv("YFS_IGEMM_TILE"); return e ? atoi(e) : 0; }();
+    const int force = yfs_knob(YFS_KNOB_IGEMM_TILE);
     if (g.NOUT % 192 == 0 && g.NOUT % 128 != 0 && force != 64) return launch_igemm<128, 192, 2, 2, 2, EPI, SUB>(g, s, name);
     if (g.NOUT % 128 != 0) return launch_igemm<128, 64, 2, 2, 2, EPI, SUB>(g, s, name);
+    if constexpr (!SUB) {
+        if (force == 8 && g.NOUT % 256 == 0) return launch_igemm8<EPI, 4>(g, s, name);
+        if (force == 87 && g.NOUT % 256 == 0) return launch_igemm8<EPI, 3>(g, s, name);
+    }
     if (force == 256) return launch_igemm<256, 128, 4, 2, 3, EPI, SUB>(g, s, name);
     if (force == 64128) return launch_igemm<64, 128, 2, 2, 2, EPI, SUB>(g, s, name);
+    if constexpr (!SUB) {
+        // 8-phase kernel (igemm8_kernel): measured on the 3x3 layers of the backbone, batch 64 — forward L7 418 -> 397 us,
+        // L18 403 -> 381, L21 100 -> 94, L24 190 -> 174; dgrad L7 455 -> 426, L18 397 -> 359, L24 206 -> 185, L10 107 -> 102;
+        // conv + pool L2 / L7 / L18 1495 -> 1414 in total.  Its main loop runs a 64-deep K-step in ~1.17 us (the rate
+        // the chip's clock under MFMA load allows), but every round of 256 tiles pays ~12 us of prologue, epilogue burst
+        // and workgroup turnover, so it needs long K and a grid that fills the CUs: K >= 2304 (1728 for the pool-fused
+        // form) and at least 200 tiles.  224 rows when that needs fewer or shorter rounds.
+        const int kdepth = g.KH * g.KW * g.C;
+        if (force == 0 && g.NOUT % 256 == 0 && kdepth >= (EPI == EPI_POOL ? 1728 : 2304)) {
+            const long long t224 = yfs_cdiv(g.M, 224) * (g.NOUT / 256), t256 = yfs_cdiv(g.M, 256) * (g.NOUT / 256);
+            const double per = kdepth / 64 * 1.17;
+            const double c224 = (double)yfs_cdiv(t224, 256) * (12.0 + per * 0.95), c256 = (double)yfs_cdiv(t256, 256) * (12.0 + per);
+            if (t224 >= 200) return c224 <= c256 ? launch_igemm8<EPI, 3>(g, s, name) : launch_igemm8<EPI, 4>(g, s, name);
+        }
+    }
     bool big = force == 2562 || force == 224, rows224 = force == 224;
     if (force == 0 && !SUB) {
         // rounds x time per round: 128x128 runs 512 tiles per round (2 per CU) in 2u, 256x256 runs 256 tiles per
@@ -955,6 +1293,289 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(WgradArgs g) {
     }
 }
 
+// ---- weight gradient on the 8-phase schedule (see igemm8_kernel) ------------------------------------------------------
+// Tile = (FX * 64 input channels) x 256 output channels of one tap, 8 waves, 64-pixel K-steps.  Half-tiles are LDS
+// images [64 pixels][128 channels] (X0 / X1 = the two halves of the ci tile, Z0 / Z1 of the co tile; for the 192-channel
+// ci tile the last 32 channel slots of each X image are never read), filled by LDS-DMA, four pixel rows per wave-
+// instruction, and read with ds_read_b64_tr_b16.  MFMA roles: A = dz fragment (co), B = x fragment (ci), so a lane ends
+// up with 4 consecutive co of one ci; the epilogue transposes through LDS and writes ci-contiguous rows, i.e. the same
+// [split][co][tap][ci] slabs as wgrad_kernel (same reduction kernel).
+// LDS: X half-tiles of both buffers in the first 64 KiB ([buf][half]), Z half-tiles in the second, so that one address
+// register per fragment reaches every half-tile of its operand through the 16-bit immediate offset.
+// The LDS-DMA is issued from inline asm here: hipcc puts s_waitcnt vmcnt(0) in front of every ds_read_b64_tr_b16 that
+// follows an LDS-DMA it knows about (it cannot tell that they touch different half-tiles), which would drain the
+// two-K-steps-deep prefetch at every phase; an asm statement is invisible to that bookkeeping, and completion is
+// counted by hand (wait_vmcnt) exactly as in igemm8_kernel.
+__device__ __forceinline__ void dma16_asm(__amdgpu_buffer_rsrc_t rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+        : "memory");
+}
+
+template <int FX>
+__global__ void __launch_bounds__(512, 2) wgrad8_kernel(WgradArgs g) {
+    constexpr int XT = FX * 64, XH = FX * 32, XCH = XH / 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int taps = g.KH * g.KW;
+    const int inner = g.citiles * taps;
+    const int logical = xcd_remap(blockIdx.x, g.cotiles * inner * g.splits);
+    const int tci = logical % inner, rest = logical / inner;
+    const int cot = rest % g.cotiles, split = rest / g.cotiles;
+    const int tap = tci / g.citiles, cit = tci % g.citiles;
+    const int kh = tap / g.KW, kw = tap % g.KW;
+    const int co0 = cot * 256, ci0 = cit * XT;
+    const int kt0 = split * g.ktiles_per_split;
+    const int kt1 = kt0 + g.ktiles_per_split < g.ktiles ? kt0 + g.ktiles_per_split : g.ktiles;
+    const int nit = kt1 - kt0;
+
+    const __amdgpu_buffer_rsrc_t srx = make_rsrc(g.x, g.xbytes), srz = make_rsrc(g.dz, g.zbytes);
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr)smem;   // LDS byte address of the ring (M0 of the LDS-DMA)
+    // staging: wave w fills pixels w*8 .. w*8+7 of every half-tile, instruction i the four pixels (w*2+i)*4 + (lane>>4),
+    // lane&15 = 16-byte LDS slot, which receives global chunk wg_swz(pixel, slot) (source-side swizzle)
+    constexpr unsigned kPixOOB = 0xFFFF0000u;
+    unsigned zoff[2], xch[2];
+    int xsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int pixel = (wave * 2 + i) * 4 + (lane >> 4);
+        const int cs = wg_swz<16>(pixel, lane & 15);
+        zoff[i] = ((unsigned)pixel * (unsigned)g.Cout + (unsigned)(co0 + cs * 8)) * 2u;
+        xch[i] = cs < XCH ? (unsigned)cs * 16u : kPixOOB;   // (192-channel tile: slots 12-15 of a row fetch nothing)
+        xsrc[i] = (i * 4 + (lane >> 4)) * 4;                // bpermute address of the lane that holds this pixel's offset
+    }
+    // lane l keeps the source offset of pixel w*8 + (l&7) of k-tile ktg + (l>>3): eight k-tiles per refresh
+    unsigned pixcache = 0;
+    auto pixel_offsets = [&](int ktg) -> unsigned {
+        const int m = (ktg + (lane >> 3)) * 64 + wave * 8 + (lane & 7);
+        const unsigned n = fdiv((unsigned)m, g.div_ohw);
+        const unsigned rem = (unsigned)m - n * g.div_ohw.d;
+        const unsigned oh = fdiv(rem, g.div_ow);
+        const unsigned ow = rem - oh * g.div_ow.d;
+        const int ih = (int)oh * g.stride - g.pad + kh * g.kh_mul, iw = (int)ow * g.stride - g.pad + kw;
+        const bool ok = m < g.M && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+        return ok ? (unsigned)((((int)n * g.H + ih) * g.W + iw) * g.PS) * 2u : kPixOOB;
+    };
+    // X source offsets of k-tile k for this lane's two LDS-DMA instructions (the same for both half-tiles): fetched from
+    // the lanes that computed them with ds_bpermute.  Done one phase before the first use, so that the LDS round trip
+    // of the permute is not between a phase's fragment reads and its DMA issue.
+    unsigned xo[2];
+    auto x_offsets = [&](int k) {   // pixcache must hold k's group of eight
+        const int grp = ((k - kt0) & 7) * 32;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned pv = (unsigned)__builtin_amdgcn_ds_bpermute(xsrc[i] + grp, (int)pixcache);
+            const unsigned sum = pv + xch[i];
+            xo[i] = (FX == 4 || xch[i] != kPixOOB) ? sum : kPixOOB;   // (OOB + OOB would wrap)
+        }
+    };
+    auto stage_X = [&](int h, int buf) {
+        const unsigned so = (unsigned)(ci0 + h * XH) * 2u;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            dma16_asm(srx, lds0 + (unsigned)((buf * 2 + h) * B8_HALF + (wave * 2 + i) * 1024), xo[i], so);
+    };
+    auto stage_Z = [&](int h, int buf, int k) {
+        const unsigned zk = (unsigned)k * (unsigned)(64 * 2) * (unsigned)g.Cout;   // in the vector offset: rows past M must
+#pragma unroll                                                                      // fall off the descriptor's end
+        for (int i = 0; i < 2; ++i) {
+            const unsigned off = zoff[i] + zk;
+            dma16_asm(srz, lds0 + (unsigned)(4 * B8_HALF + (buf * 2 + h) * B8_HALF + (wave * 2 + i) * 1024), off, (unsigned)(h * 256));
+        }
+    };
+
+    f32x4 acc[2][2][2][FX];   // [ci half][co half][co fragment][ci fragment]
+#pragma unroll
+    for (int i = 0; i < 8 * FX; ++i) (&acc[0][0][0][0])[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 accdb[2][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) (&accdb[0][0])[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.0f;
+    const bool do_db = g.dbpart != nullptr;
+    int dbc = kt0 % inner;
+
+    // transposed-read geometry (see wgrad_kernel)
+    const int g4 = lane >> 4, li = lane & 15;
+    const int tr_pix = 8 * g4 + (li >> 2), tr_ch = 4 * (li & 3);
+    typedef bf16x4 __attribute__((address_space(3)))* tr_ptr;
+    bf16x8 xf[FX][2], zf[2][2];   // (Z0 is read again in phase 4 rather than kept: 16 registers)
+    // one address per (fragment, pixel group 0-3 / 4-7); K-half, half-tile and buffer are immediate offsets
+    const unsigned char* xa[FX][2];
+    const unsigned char* za[2][2];
+#pragma unroll
+    for (int hl = 0; hl < 2; ++hl) {
+#pragma unroll
+        for (int b = 0; b < FX; ++b) xa[b][hl] = smem + wg_addr<16>(tr_pix + 4 * hl, wm * (FX * 16) + b * 16 + tr_ch);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) za[a][hl] = smem + 4 * B8_HALF + wg_addr<16>(tr_pix + 4 * hl, wn * 32 + a * 16 + tr_ch);
+    }
+    auto read_frag = [&](const unsigned char* lo_addr, const unsigned char* hi_addr, int off) -> bf16x8 {
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tr_ptr)(lo_addr + off));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tr_ptr)(hi_addr + off));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto read_X = [&](int hoff) {   // hoff = (buf * 2 + half) * B8_HALF; a K-half is 32 pixel rows of 256 B further on
+#pragma unroll
+        for (int b = 0; b < FX; ++b)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) xf[b][ks] = read_frag(xa[b][0], xa[b][1], hoff + ks * 8192);
+    };
+    auto read_Z = [&](int hoff) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) zf[a][ks] = read_frag(za[a][0], za[a][1], hoff + ks * 8192);
+    };
+    auto mfma_q = [&](f32x4 (&c)[2][FX], const bf16x8 (&zf)[2][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < FX; ++b) c[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf[a][ks], xf[b][ks], c[a][b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // bias gradient: column sums of dz as MFMAs against ones; the `inner` workgroups that share a dz slab take every
+    // inner-th k-tile each and the two wave rows one 32-pixel half each (as wgrad_kernel)
+    auto mfma_db = [&](f32x4 (&c)[2], const bf16x8 (&zf)[2][2]) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+            c[a] = wm == 0 ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf[a][0], ones, c[a], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf[a][1], ones, c[a], 0, 0, 0);
+    };
+    auto lgkm0 = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+    auto bar = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // phases (staging order differs from igemm8_kernel because Z0 is read twice):
+    //   1: read Z0, X0 | stage Z0 of tile t+1 | MFMA (X0, Z0)      3: read X1 | stage Z1 of tile t+2 | MFMA (X1, Z1)
+    //   2: read Z1     | stage X0 of tile t+2 | MFMA (X0, Z1)      4: read Z0 | stage X1 of tile t+2, vmcnt | MFMA (X1, Z0)
+    // every half-tile is restaged one phase after its last read, which the lgkmcnt(0) before the barrier has retired
+    pixcache = pixel_offsets(kt0);
+    x_offsets(kt0);
+    stage_Z(0, 0, kt0); stage_X(0, 0); stage_Z(1, 0, kt0); stage_X(1, 0);
+    if (nit > 1) {
+        x_offsets(kt0 + 1);
+        stage_X(0, 1); stage_Z(1, 1, kt0 + 1); stage_X(1, 1);   // (Z0 of tile 1: phase 1 of tile 0)
+        wait_vmcnt<6>();
+    } else {
+        wait_vmcnt<0>();
+    }
+    bar();
+    if (wm == 1) bar();
+
+    auto tile = [&](int t, auto buf_tag) {
+        constexpr int BUF = decltype(buf_tag)::value;
+        const bool dbmode = do_db && dbc == tci;
+        dbc = dbc + 1 == inner ? 0 : dbc + 1;
+        const int k1 = kt0 + t + 1, k2 = kt0 + t + 2;
+        // phase 1
+        read_Z((BUF * 2) * B8_HALF);
+        read_X((BUF * 2) * B8_HALF);
+        if (k1 < kt1) stage_Z(0, BUF ^ 1, k1);
+        if (k2 < kt1) {
+            if (((k2 - kt0) & 7) == 0) pixcache = pixel_offsets(k2);
+            x_offsets(k2);
+        }
+        lgkm0();
+        bar();
+        mfma_q(acc[0][0], zf);
+        if (dbmode) mfma_db(accdb[0], zf);
+        bar();
+        // phase 2
+        read_Z((BUF * 2 + 1) * B8_HALF);
+        if (k2 < kt1) stage_X(0, BUF);
+        lgkm0();
+        bar();
+        mfma_q(acc[0][1], zf);
+        if (dbmode) mfma_db(accdb[1], zf);
+        bar();
+        // phase 3
+        read_X((BUF * 2 + 1) * B8_HALF);
+        if (k2 < kt1) stage_Z(1, BUF, k2);
+        lgkm0();
+        bar();
+        mfma_q(acc[1][1], zf);
+        bar();
+        // phase 4
+        read_Z((BUF * 2) * B8_HALF);
+        if (k2 < kt1) {
+            stage_X(1, BUF);
+            wait_vmcnt<6>();
+        } else {
+            wait_vmcnt<0>();
+        }
+        lgkm0();
+        bar();
+        mfma_q(acc[1][0], zf);
+        bar();
+    };
+    int t = 0;
+    for (; t + 1 < nit; t += 2) {
+        tile(t, std::integral_constant<int, 0>());
+        tile(t + 1, std::integral_constant<int, 1>());
+    }
+    if (t < nit) tile(t, std::integral_constant<int, 0>());
+    if (wm == 0) bar();
+
+    // ---- epilogue: transpose through LDS, four slabs of 64 co rows; rows leave as whole ci-contiguous runs --------------
+    // acc[xh][zh][a][b][r] = dw[co0 + zh*128 + wn*32 + a*16 + (lane>>4)*4 + r][tap][ci0 + xh*XH + wm*FX*16 + b*16 + (lane&15)]
+    constexpr int ESTRIDE = XT * 4 + 16;   // bytes per staged co row (the +16 keeps the 4-row groups of a store on distinct banks)
+    const long long kw_tot = (long long)taps * g.Cin;
+    float* pbase = g.partial + (long long)split * g.Cout * kw_tot;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        if ((wn >> 1) == (pass & 1)) {
+#pragma unroll
+            for (int xh = 0; xh < 2; ++xh)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < FX; ++b) {
+                        const int row = (wn & 1) * 32 + a * 16 + g4 * 4;
+                        const int ci = xh * XH + wm * (FX * 16) + b * 16 + li;
+                        const f32x4 v = acc[xh][pass >> 1][a][b];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) *reinterpret_cast<float*>(smem + (row + r) * ESTRIDE + ci * 4) = v[r];
+                    }
+        }
+        __syncthreads();
+        constexpr int C4 = XT / 4;   // float4 per row
+        for (int item = tid; item < 64 * C4; item += 512) {
+            const int row = item / C4, c4 = item - row * C4;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * ESTRIDE + c4 * 16);
+            const int co = co0 + pass * 64 + row;
+            *reinterpret_cast<f32x4*>(pbase + (long long)co * kw_tot + (long long)tap * g.Cin + ci0 + c4 * 4) = v;
+        }
+        if (pass < 3) __syncthreads();
+    }
+    if (do_db && li == 0) {   // every column of accdb holds the same sums: column 0 (lanes 0, 16, 32, 48) writes
+        float* drow = g.dbpart + ((long long)(split * inner + tci) * 2 + wm) * g.Cout;
+#pragma unroll
+        for (int zh = 0; zh < 2; ++zh)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) drow[co0 + zh * 128 + wn * 32 + a * 16 + g4 * 4 + r] = accdb[zh][a][r];
+    }
+}
+
 // dw[i] = (accumulate ? dw[i] : 0) + sum_s partial[s][i].  G groups of threads share one float4 column: group r
 // sums slabs r, r+G, ... and the G sums are combined through LDS in fixed order (deterministic).  Small outputs
 // with many slabs (1x1 layers: 32K floats x 224 slabs) would otherwise run on a few dozen serial threads.
@@ -1038,16 +1659,52 @@ __global__ void __launch_bounds__(kThreads) splitk_reduce_kernel(const float4* _
 
 struct WgradPlan {
     int bx, bz, cotiles, citiles, splits, ktiles, ktiles_per_split, db_splits;
+    bool use8;   // wgrad8_kernel (256-wide co tile, 256- or 192-wide ci tile, one workgroup per CU)
     size_t partial_bytes, db_bytes;
 };
 
 // taps = KH*KW.  Tile widths: 128 where the channel count allows, 192 for the two 192-channel tensors of the
 // backbone (feat.2's input, feat.0's output), else 64.  Only the instantiated (bx, bz) pairs are produced.
-WgradPlan plan_wgrad(int64_t M, int Cin, int Cout, int taps, bool wide192 = false) {
+WgradPlan plan_wgrad(int64_t M, int Cin, int Cout, int taps, bool wide192 = false, bool plain = true) {
     WgradPlan p;
+    p.use8 = false;
+    const int force_tile8 = yfs_knob(YFS_KNOB_WGRAD_TILE);
+    if (plain && !wide192 && Cout % 256 == 0 && (Cin % 256 == 0 || Cin == 192) &&
+        (force_tile8 == 8 || (force_tile8 == 0 && taps > 1 && Cin % 256 == 0))) {
+        // 8-phase kernel: one workgroup per CU, so the grid runs in rounds of 256; same cost model as below
+        p.use8 = true;
+        p.bx = Cin % 256 == 0 ? 256 : 192;
+        p.bz = 256;
+        p.citiles = Cin / p.bx;
+        p.cotiles = Cout / 256;
+        p.ktiles = (int)yfs_cdiv(M, 64);
+        const int tiles = p.citiles * p.cotiles * taps;
+        const int max_splits = p.ktiles / 8 > 0 ? p.ktiles / 8 : 1;
+        // (measured: L7 561 -> 437 us, L10 147 -> 126, L18 587 -> 455, L21 164 -> 132, L24 312 -> 246, L25 / L26 112 -> 95;
+        //  the 1x1 layers and the 192-channel ci tile of L2 are slower than wgrad_kernel and stay there unless forced)
+        const double t_tile = p.bx == 256 ? 1.50 : 1.35;                      // us per 64-pixel k-tile
+        const double t_slab = (double)Cout * taps * Cin * 8.0 / 4.0e6;        // us per partial copy (write + read at 4 TB/s)
+        double best = 1e30;
+        int best_per = p.ktiles;
+        for (int sp = 1; sp <= max_splits && sp <= 1024; ++sp) {
+            const int per = (int)yfs_cdiv(p.ktiles, sp);
+            const int real = (int)yfs_cdiv(p.ktiles, per);
+            const long long rounds = yfs_cdiv((long long)tiles * real, 256);
+            const double t = (double)rounds * (per * t_tile + 8.0) + (real > 1 ? real * t_slab : 0.0);
+            if (t < best) { best = t; best_per = per; }
+        }
+        const int fs = yfs_knob(YFS_KNOB_WGRAD_SPLITS);
+        if (fs > 0) best_per = (int)yfs_cdiv(p.ktiles, fs < p.ktiles ? fs : p.ktiles);
+        p.ktiles_per_split = best_per;
+        p.splits = (int)yfs_cdiv(p.ktiles, p.ktiles_per_split);
+        p.partial_bytes = (size_t)p.splits * Cout * taps * Cin * sizeof(float);
+        p.db_splits = p.splits * p.citiles * taps * 2;
+        p.db_bytes = (size_t)p.db_splits * Cout * sizeof(float);
+        return p;
+    }
     p.bx = (Cin % 128 == 0) ? 128 : ((Cin % 192 == 0 && Cout % 128 == 0) ? 192 : 64);
     p.bz = (Cout % 128 == 0) ? 128 : ((Cout % 192 == 0 && (p.bx == 64 || wide192)) ? 192 : 64);
-    static const int force_tile = [] { const char* e = getenv("YFS_WGRAD_TILE"); return e ? atoi(e) : 0; }();   // sweeps
+    const int force_tile = yfs_knob(YFS_KNOB_WGRAD_TILE);   // sweeps
     if (force_tile == 64 && !wide192) p.bx = p.bz = 64;
     if (force_tile == 12864 && !wide192 && p.bx == 128 && p.bz == 128) p.bz = 64;
     p.citiles = Cin / p.bx;
@@ -1070,7 +1727,7 @@ WgradPlan plan_wgrad(int64_t M, int Cin, int Cout, int taps, bool wide192 = fals
         const double t = (double)rounds * (per * t_tile + 3.0) + real * t_slab;
         if (t < best) { best = t; best_per = per; }
     }
-    static const int force_splits = [] { const char* e = getenv("YFS_WGRAD_SPLITS"); return e ? atoi(e) : 0; }();   // sweeps
+    const int force_splits = yfs_knob(YFS_KNOB_WGRAD_SPLITS);   // sweeps
     if (force_splits > 0) best_per = (int)yfs_cdiv(p.ktiles, force_splits < p.ktiles ? force_splits : p.ktiles);
     p.ktiles_per_split = best_per;
     p.splits = (int)yfs_cdiv(p.ktiles, p.ktiles_per_split);
@@ -1078,6 +1735,17 @@ WgradPlan plan_wgrad(int64_t M, int Cin, int Cout, int taps, bool wide192 = fals
     p.db_splits = p.splits * p.citiles * taps * 2;   // one partial row per (split, tap, ci tile, wave row)
     p.db_bytes = (size_t)p.db_splits * Cout * sizeof(float);
     return p;
+}
+
+template <int FX>
+int launch_wgrad8(WgradArgs& g, const WgradPlan& p, hipStream_t s) {
+    auto kern = wgrad8_kernel<FX>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, B8_LDS);
+    YFS_REQUIRE(e == hipSuccess, YFS_ERR_LAUNCH, "yfs_conv2d_wgrad_bf16: cannot reserve %d bytes of LDS", B8_LDS);
+    const int nblk = p.cotiles * p.citiles * g.KH * g.KW * p.splits;
+    kern<<<dim3((unsigned)nblk), dim3(512), B8_LDS, s>>>(g);
+    YFS_CHECK_LAUNCH("wgrad8_kernel");
+    return YFS_OK;
 }
 
 template <int BX, int BZ, bool POOLZ = false, bool SGD = false>
@@ -1112,7 +1780,8 @@ int wgrad_common(const char* fn, const void* x, const void* dz, float* dw, float
                  float slope = 0.0f, unsigned xgroup_bytes = 128, int kh_mul = 1) {
     const int64_t M = N * OH * OW;
     const int taps = KH * KW;
-    WgradPlan p = plan_wgrad(M, Cin, Cout, taps, pool_idx != nullptr);
+    const bool plain = pool_idx == nullptr && xgroup_bytes == 128 && kh_mul == 1 && PS == Cin;
+    WgradPlan p = plan_wgrad(M, Cin, Cout, taps, pool_idx != nullptr, plain);
     YFS_REQUIRE(workspace && workspace_bytes >= p.partial_bytes + p.db_bytes, YFS_ERR_WORKSPACE,
                 "%s: workspace needs %zu bytes, got %zu", fn, p.partial_bytes + p.db_bytes, workspace_bytes);
     YFS_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, YFS_ERR_WORKSPACE, "%s: workspace must be 16-byte aligned", fn);
@@ -1127,6 +1796,9 @@ int wgrad_common(const char* fn, const void* x, const void* dz, float* dw, float
     g.ktiles_per_split = p.ktiles_per_split;
     g.div_ohw = make_fastdiv((unsigned)(OH * OW)); g.div_ow = make_fastdiv((unsigned)OW);
     int rc;
+    if (p.use8) {
+        rc = p.bx == 256 ? launch_wgrad8<4>(g, p, s) : launch_wgrad8<3>(g, p, s);
+    } else
     if (pool_idx) {   // dz given as (pooled gradient, argmax record, pooled activation): see wgrad_kernel POOLZ
         YFS_REQUIRE(p.bx == 128 && OH % 2 == 0 && OW % 2 == 0, YFS_ERR_UNSUPPORTED,
                     "%s: the pooled-gradient form needs a 128-wide reduction tile and an even %dx%d output", fn, OH, OW);
@@ -1212,7 +1884,7 @@ YFS_API int yfs_linear_wgrad_sgd_bf16(const void* x, const void* dy, int64_t B, 
 // implicit GEMM runs with KH=4, KW=1, C=64, pixel stride 16 and never materialises an im2col matrix.
 namespace {
 constexpr int kStemC = 16, kStemKH = 4;
-static int stem_ps() { static const int v = [] { const char* e = getenv("YFS_STEM_PS_EXPERIMENT"); return e ? atoi(e) : kStemC; }(); return v; }
+static int stem_ps() { return kStemC; }
 int stem_check(const char* fn, int64_t N, int Hs, int Ws, int OH, int OW, int Cout) {
     YFS_REQUIRE(N > 0 && Hs > 0 && Ws > 0 && OH > 0 && OW > 0 && Cout > 0, YFS_ERR_INVALID_ARG, "%s: non-positive dimension", fn);
     YFS_REQUIRE(OH + 3 <= Hs && OW + 4 <= Ws, YFS_ERR_INVALID_ARG,

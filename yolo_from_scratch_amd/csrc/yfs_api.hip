@@ -1,7 +1,9 @@
-// libyfs.so: version + thread-local error reporting.
+// libyfs.so: version, thread-local error reporting, tuning knobs.
 #include "yfs_common.h"
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 static thread_local char g_err[512] = {0};
@@ -13,7 +15,7 @@ void yfs_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-YFS_API int yfs_version(void) { return 100; }
+YFS_API int yfs_version(void) { return 200; }
 
 YFS_API int yfs_last_error(char* buf, size_t n) {
     size_t len = strlen(g_err);
@@ -23,4 +25,36 @@ YFS_API int yfs_last_error(char* buf, size_t n) {
         buf[c] = 0;
     }
     return (int)len;
+}
+
+// ---- tuning knobs (include/yfs.h: measurement aids; the library's only process-wide mutable state) ------------------
+namespace {
+std::atomic<int> g_knob[YFS_KNOB_COUNT];
+std::atomic<int> g_knob_init{0};
+const char* const kKnobEnv[YFS_KNOB_COUNT] = {"YFS_IGEMM_TILE", "YFS_WGRAD_TILE", "YFS_WGRAD_SPLITS", "YFS_NMS_FUSED"};
+void knob_init() {   // the environment gives the initial values, read once (racing first calls write the same values)
+    if (g_knob_init.load(std::memory_order_acquire)) return;
+    for (int k = 0; k < YFS_KNOB_COUNT; ++k) {
+        const char* e = getenv(kKnobEnv[k]);
+        g_knob[k].store(e ? atoi(e) : 0, std::memory_order_relaxed);
+    }
+    g_knob_init.store(1, std::memory_order_release);
+}
+}  // namespace
+
+int yfs_knob(int knob) {
+    knob_init();
+    return (knob >= 0 && knob < YFS_KNOB_COUNT) ? g_knob[knob].load(std::memory_order_relaxed) : 0;
+}
+
+YFS_API int yfs_get_knob(int knob) {
+    YFS_REQUIRE(knob >= 0 && knob < YFS_KNOB_COUNT, YFS_ERR_INVALID_ARG, "yfs_get_knob: unknown knob %d", knob);
+    return yfs_knob(knob);
+}
+
+YFS_API int yfs_set_knob(int knob, int value) {
+    YFS_REQUIRE(knob >= 0 && knob < YFS_KNOB_COUNT, YFS_ERR_INVALID_ARG, "yfs_set_knob: unknown knob %d", knob);
+    knob_init();
+    g_knob[knob].store(value, std::memory_order_relaxed);
+    return YFS_OK;
 }
