@@ -34,6 +34,10 @@ BATCH = 64
 LOSS_BYTES_PER_IMG = 17640    # read pred + read target + write grad, 3 x 1470 x 4
 ASSIGN_BYTES_PER_IMG = 32750  # gts 640 + decoded preds 13,520 + masks 1,690 + targets 16,900
 NMS_BYTES_PER_IMG = 108160    # raw head 84,500 + boxes/score/class 20,280 + kept indices 3,380
+# HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled
+# per the gfx950 note of MI355X_MICROARCH.md; profiles/r02/pmc_traffic_hbm_kernels.txt), at the sub-benchmarks' own sizes.
+# bench.py cannot run rocprofv3 on itself, so these are the committed measurements, not live values.
+PMC_TRAFFIC_BYTES = {"nms": 109.0e6, "loss": 1.13e9, "assign": 264.0e6}
 
 
 def conv_flops_table(model, batch, hw=448):
@@ -93,14 +97,14 @@ class ConvTimers:
 
 
 def cpu_baseline_train(sample_batch=4, steps=2):
-    """The oracle's train step (torch-CPU fp32 restatement of the reference step + C composite loss) on the host."""
+    """The oracle's train step (torch-CPU fp32 restatement of the reference step + C composite loss) on the host:
+    once on the threads this job may use (OMP_NUM_THREADS on the GPU box = its CPU share) and once on 8 threads, the
+    count SURVEY.md 8(d) anchors its own measurement on."""
     import oracle
     from oracle import model_ref
     from yolo_from_scratch_amd import synth
     cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16") or 16))
-    torch.set_num_threads(cores)
     params = model_ref.init_params(seed=0, head_out=1470)
-    bufs = {}
     x = torch.rand(sample_batch, 3, 448, 448, generator=torch.Generator().manual_seed(0))
     tgt = synth.v1_targets(sample_batch, seed=1)
 
@@ -116,14 +120,52 @@ def cpu_baseline_train(sample_batch=4, steps=2):
             return ctx.g * go
 
     loss_fn = lambda out, _t: _OracleLoss.apply(out)   # noqa: E731
-    model_ref.train_step(params, bufs, x, None, loss_fn)          # warm-up (allocations, oneDNN primitive cache)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        model_ref.train_step(params, bufs, x, None, loss_fn)
-    dt = time.perf_counter() - t0
-    return {"value": round(sample_batch * steps / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
+
+    def timed(threads):
+        torch.set_num_threads(threads)
+        bufs = {}
+        model_ref.train_step(params, bufs, x, None, loss_fn)          # warm-up (allocations, oneDNN primitive cache)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            model_ref.train_step(params, bufs, x, None, loss_fn)
+        return sample_batch * steps / (time.perf_counter() - t0)
+    v = timed(cores)
+    v8 = timed(min(8, cores)) if cores != 8 else v
+    return {"value": round(v, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "value_8_threads": round(v8, 3), "host_cpu_count": os.cpu_count(), "host_cpu": _cpu_model(),
             "sample": f"{steps} train steps at batch {sample_batch}, 448x448, fp32 torch-CPU restatement "
-                      f"(oracle/model_ref.py + oracle yolov1_loss), 1 warm-up step untimed, on {_cpu_model()}"}
+                      f"(oracle/model_ref.py + oracle yolov1_loss), 1 warm-up step untimed, on {cores} threads "
+                      f"(the job's CPU share; os.cpu_count() = {os.cpu_count()}) and again on 8 threads"}
+
+
+def cpu_baseline_loss(sample=2048):
+    import oracle
+    from yolo_from_scratch_amd import synth
+    t = synth.v1_targets(sample, seed=1)
+    p = np.random.default_rng(3).uniform(0, 1, t.shape).astype(np.float32)
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < 2.0:
+        oracle.yolov1_loss(p, t)
+        reps += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(sample * reps / dt, 1), "unit": "images/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} passes over {sample} images (C oracle orc_yolov1_loss, scalar) on {_cpu_model()}"}
+
+
+def cpu_baseline_assign(sample=1024, S=13, G=32):
+    import oracle
+    from yolo_from_scratch_amd import synth
+    gt = synth.gt_boxes(sample, G=G, seed=5)
+    pred = np.random.default_rng(6).uniform(0.05, 0.9, (sample, S * S * 5, 4)).astype(np.float32)
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < 2.0:
+        oracle.assign_targets_v2(gt, synth.VOC_ANCHORS, S, pred, 0.6)
+        reps += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(sample * reps / dt, 1), "unit": "images/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} passes over {sample} images (C oracle orc_assign_targets_v2, scalar) on {_cpu_model()}"}
 
 
 def nms_bench(device, iters=20):
@@ -164,10 +206,11 @@ def _time_ms(fn, iters, warm=3):
     return e0.elapsed_time(e1) / iters
 
 
-def _hbm_record(nbytes, ms):
+def _hbm_record(nbytes, ms, traffic=None):
     gbs = nbytes / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": round(gbs, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-            "frac": round(gbs / PEAK_HBM_GBS, 5), "traffic": None}
+            "frac": round(gbs / PEAK_HBM_GBS, 5), "traffic": traffic,
+            "traffic_source": "profiles/r02/pmc_traffic_hbm_kernels.txt (bytes per launch)" if traffic else None}
 
 
 def loss_bench(device, N=65536):
@@ -190,7 +233,7 @@ def loss_bench(device, N=65536):
     ms = _time_ms(run, 20)
     return {"metric": "fused YOLOv1 loss + gradient images/sec (S=7 B=2 C=20, batch %d)" % N,
             "value": round(N / (ms * 1e-3), 1), "unit": "images/s", "ms_per_batch": round(ms, 4), "dtype": "f32",
-            "roofline": _hbm_record(N * LOSS_BYTES_PER_IMG, ms)}
+            "roofline": _hbm_record(N * LOSS_BYTES_PER_IMG, ms, PMC_TRAFFIC_BYTES["loss"] if N == 65536 else None)}
 
 
 def assign_bench(device, N=8192, S=13, G=32):
@@ -203,7 +246,7 @@ def assign_bench(device, N=8192, S=13, G=32):
     ms = _time_ms(lambda: y.assign_targets_v2(gt, anchors, S, pred, 0.6), 20)
     return {"metric": "YOLOv2 target assignment images/sec (S=13, A=5, G=32, batch %d)" % N,
             "value": round(N / (ms * 1e-3), 1), "unit": "images/s", "ms_per_batch": round(ms, 4), "dtype": "f32",
-            "roofline": _hbm_record(N * ASSIGN_BYTES_PER_IMG, ms)}
+            "roofline": _hbm_record(N * ASSIGN_BYTES_PER_IMG, ms, PMC_TRAFFIC_BYTES["assign"] if (N, S, G) == (8192, 13, 32) else None)}
 
 
 def measured_ceilings(device):
@@ -273,6 +316,10 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
+        # A stalled collective must end the run with a diagnosis, not a silent driver timeout: every rank dumps the
+        # stacks of all its threads to stderr and exits non-zero if the whole run takes longer than this.
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get("YFS_BENCH_WATCHDOG_S", "420")), exit=True)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
 
@@ -362,7 +409,7 @@ def main():
                                           (" buckets; fc.1 as all-gathered gradient factors" if opt._defer else ""))
                        if world > 1 else None},
             "final_loss": round(final_loss, 5),
-            "roofline": {"bound": "mfma", "kernel": "conv implicit-GEMM set (igemm_kernel fwd+dgrad, wgrad_kernel)",
+            "roofline": {"bound": "mfma", "kernel": "conv implicit-GEMM set (igemm_kernel / igemm8_kernel fwd+dgrad, wgrad_kernel / wgrad8_kernel)",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
                          "algorithmic_tflop_per_step": round(conv_flops / 1e12, 4), "conv_ms_per_step": round(conv_ms, 3),
@@ -376,6 +423,9 @@ def main():
                 rec["nms"]["cpu_baseline"] = cpu_baseline_nms()
             rec["loss"] = loss_bench(device)
             rec["assign"] = assign_bench(device)
+            if not args.no_cpu_baseline:
+                rec["loss"]["cpu_baseline"] = cpu_baseline_loss()
+                rec["assign"]["cpu_baseline"] = cpu_baseline_assign()
             rec["roofline"]["measured_ceilings"] = measured_ceilings(device)
         if world == 1 and not args.no_cpu_baseline:
             del model, opt
@@ -385,6 +435,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+        import faulthandler
+        faulthandler.cancel_dump_traceback_later()
 
 
 if __name__ == "__main__":

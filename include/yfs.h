@@ -45,7 +45,7 @@ int yfs_last_error(char *buf, size_t n);
  * values come from the environment variables of the same name (YFS_IGEMM_TILE, YFS_WGRAD_TILE, YFS_WGRAD_SPLITS,
  * YFS_NMS_FUSED), read once at the first use of any knob.  Changing a knob while another thread launches kernels
  * affects that thread's tile choice, never its results beyond fp32 summation order.
- *   YFS_KNOB_IGEMM_TILE    forward/dgrad workgroup tile: 128 | 64128 | 224 | 2562 | 256 | 8 (256x256, 8-phase schedule)
+ *   YFS_KNOB_IGEMM_TILE    forward/dgrad workgroup tile: 128 | 64128 | 224 | 2562 | 256 | 8 (256x256, 8-phase) | 87 (224x256, 8-phase)
  *   YFS_KNOB_WGRAD_TILE    weight-gradient tile: 64 | 12864 | 8 (256x256, 8-phase schedule)
  *   YFS_KNOB_WGRAD_SPLITS  split-K factor of the weight gradient (> 0 forces it)
  *   YFS_KNOB_NMS_FUSED     1: yfs_decode_nms_f32 decodes inside the NMS kernel (one launch) */
@@ -138,6 +138,15 @@ int yfs_mse_fwd_bwd_f32(const float *pred, const float *target, int64_t n, float
  * below, or through yfs_im2col_bf16 first). */
 int yfs_conv2d_fwd_bf16(const void *x, const void *w, const float *bias, void *y, int64_t N, int H, int W,
                         int Cin, int Cout, int K, int stride, float slope, void *stream);
+/* Conv + BatchNorm (inference statistics) + LeakyReLU in one launch: y = leaky(conv(x, w) * scale[c] + shift[c]).
+ * The reference's block has no BatchNorm (yolo_toy_regressor_torch.py:208-211); it is the YOLOv2 step its roadmap
+ * names (README.md:30, what_to_change_next.txt:83).  scale = gamma / sqrt(var + eps), shift = beta + (conv_bias -
+ * mean) * scale, both [Cout] fp32, applied in fp32 before the one rounding to bf16.  scale == NULL means 1: that
+ * IS yfs_conv2d_fwd_bf16 (shift = bias), bit for bit.  Inference-time folding only: there is no backward through the
+ * statistics; to train through a frozen BatchNorm fold scale into the weights (w * scale[co], shift as the bias) and use
+ * the ordinary forward / dgrad / wgrad entry points. */
+int yfs_conv2d_fwd_affine_bf16(const void *x, const void *w, const float *scale, const float *shift, void *y, int64_t N,
+                               int H, int W, int Cin, int Cout, int K, int stride, float slope, void *stream);
 /* dx = conv_transpose(dz, w) [* leaky'(x_act) when x_act != NULL].  dz [N,Ho,Wo,Cout] bf16,
  * wt [Cin,K,K,Cout] bf16 = w transposed and spatially flipped (yfs_weight_prep), dx [N,H,W,Cin] bf16.
  * x_act: this layer's input when it is itself a LeakyReLU output, so the previous block's

@@ -303,3 +303,26 @@ def test_wgrad_8phase_kernel_matches_default(n, cin, cout, k, s, hw):
         tolb = 2e-5 * float(db_ref.abs().max()) + 1e-6
         assert float((db - db_ref).abs().max()) <= tolb
         assert float((db2 - 2 * db_ref).abs().max()) <= 2 * tolb
+
+
+@pytest.mark.parametrize("n,cin,cout,k,s,hw", [(2, 64, 128, 3, 1, 12), (1, 128, 256, 1, 1, 14), (2, 64, 192, 3, 2, 16),
+                                               (64, 64, 256, 3, 1, 28)])
+def test_conv_folded_batchnorm_leaky_epilogue(n, cin, cout, k, s, hw):
+    """Conv + BatchNorm (eval statistics) + LeakyReLU as one launch (north_star's block; README.md:30 of the reference)
+    against torch-CPU conv2d -> batch_norm(training=False) -> leaky_relu on the same bf16-rounded operands, 1e-2; and
+    scale = None reproduces the reference's bias-only block bit for bit.  The last shape runs on the 8-phase kernel."""
+    x, w, b = _case(n, cin, cout, k, hw, seed=cin + cout + hw)
+    g = torch.Generator().manual_seed(9)
+    bn = torch.nn.BatchNorm2d(cout).eval()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(cout, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(cout, generator=g) * 0.1)
+        bn.running_mean.copy_(torch.randn(cout, generator=g) * 0.2)
+        bn.running_var.copy_(torch.rand(cout, generator=g) + 0.3)
+        ref = F.leaky_relu(bn(F.conv2d(x, w, b, stride=s, padding=k // 2)), 0.1)
+    xd = co.nhwc(x.to(DEV), torch.bfloat16)
+    w16, _ = co.weight_prep(co.nhwc(w.to(DEV)), want_wt16=False)
+    scale, shift = co.fold_batchnorm(bn, b)
+    y = co.conv_fwd_affine(xd, w16, scale.to(DEV), shift.to(DEV), s)
+    _close(y, ref, "conv + folded BN + leaky")
+    assert torch.equal(co.conv_fwd_affine(xd, w16, None, b.to(DEV), s), co.conv_fwd(xd, w16, b.to(DEV), s))

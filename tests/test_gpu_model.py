@@ -311,7 +311,7 @@ def test_deferred_linear_gradient_under_data_parallel_exchange(monkeypatch):
         for o in outs:
             o.copy_(t)
 
-    def fake_all_reduce(t, op=None, group=None):
+    def fake_all_reduce(t, op=None, group=None, async_op=False):
         t.mul_(world)
     monkeypatch.setattr(dp.dist, "all_gather", fake_all_gather)
     monkeypatch.setattr(dp.dist, "all_reduce", fake_all_reduce)

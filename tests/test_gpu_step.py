@@ -1,0 +1,197 @@
+"""The composed train step (reference yolo_toy_regressor_torch.py:314-339: zero_grad, forward, loss, backward,
+clip_grad_norm_(1.0), SGD momentum step) on the MI355X against oracle.model_ref.train_step, plus the checks that the
+two-stream backward is race-free (bitwise re-run), that an enabled GradScaler leaves the trajectory unchanged, and
+that the data-parallel exchange drives the whole Backbone + fc model correctly."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import model_ref
+import yolo_from_scratch_amd as y
+from yolo_from_scratch_amd import model as ym
+from yolo_from_scratch_amd import synth
+from yolo_from_scratch_amd import train as yt
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+class _OracleV1Loss(torch.autograd.Function):
+    """oracle.yolov1_loss (C, fp32) as a torch-CPU loss for model_ref.train_step."""
+
+    @staticmethod
+    def forward(ctx, out, target):
+        lo, g = oracle.yolov1_loss(out.detach().numpy().reshape(-1, 7, 7, 30), target)
+        ctx.g = torch.from_numpy(g.reshape(out.shape))
+        return torch.tensor(float(lo[0]))
+
+    @staticmethod
+    def backward(ctx, go):
+        return ctx.g * go, None
+
+
+@pytest.mark.parametrize("head", ["mse4", "yolov1"])
+def test_two_full_steps_match_the_oracle_step(head):
+    """Two full steps at 64x64, batch 8, dropout off: feat + fc with (a) the reference's own head and loss (4 outputs,
+    MSE, :255-264, :377) and (b) the 1470-output head with the composite loss.  Updated parameters and momentum
+    buffers against oracle.model_ref.train_step (torch-CPU fp32).  Tolerance: the step is lr * (clipped gradient +
+    weight decay), and the gradient has passed 24 bf16 layers twice, so the UPDATE (p_after - p_before) is compared at
+    the bf16 end-to-end tolerance this suite uses for the forward (4e-2, test_gpu_model.py) relaxed to 8e-2 for the
+    backward chain, per parameter group with a meaningful update; losses at 4e-2."""
+    head_out = 4 if head == "mse4" else 1470
+    params = model_ref.init_params(seed=0, head_out=head_out, in_hw=64)
+    torch.manual_seed(0)
+    net = ym.YoloRegressorModel(head_out=head_out, image_size=64, p_drop=0.0).to(DEV)
+    for k, v in net.state_dict().items():
+        assert torch.equal(v.cpu().contiguous(), params[k]), k
+    opt = yt.FlatSGD(net.parameters(), lr=1e-3, momentum=0.9, weight_decay=5e-4, max_norm=1.0)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(8, 3, 64, 64, generator=g)
+    if head == "mse4":
+        tgt = torch.rand(8, 4, generator=g) * 0.5 + 0.25
+        loss_gpu, loss_cpu = y.MSELoss(), torch.nn.MSELoss()
+        tgt_cpu = tgt
+    else:
+        tnp = synth.v1_targets(8, seed=2)
+        tgt = torch.from_numpy(tnp)
+        loss_gpu = y.YoloV1Loss(7, 2, 20)
+        loss_cpu = lambda out, t: _OracleV1Loss.apply(out, tnp)   # noqa: E731
+        tgt_cpu = None
+    before = {k: v.clone() for k, v in params.items()}
+    bufs = {}
+    names = [k for k, _ in net.named_parameters()]
+    for step in range(2):
+        lo = model_ref.train_step(params, bufs, x, tgt_cpu, loss_cpu, lr=1e-3)
+        opt.zero_grad()
+        loss = loss_gpu(net(x.to(DEV)), tgt.to(DEV))
+        loss.backward()
+        opt.step()
+        assert abs(float(loss) - lo) <= 4e-2 * abs(lo) + 1e-4, (step, float(loss), lo)
+    sd = {k: v.detach().cpu().contiguous() for k, v in net.state_dict().items()}
+    checked = 0
+    for i, k in enumerate(names):
+        upd_ref = params[k] - before[k]
+        upd = sd[k] - before[k]
+        if float(upd_ref.norm()) < 1e-7:
+            continue
+        assert _rel(upd, upd_ref) < 8e-2, (k, _rel(upd, upd_ref))
+        o, n = opt.offsets[i]
+        m_gpu = torch.as_strided(opt.flat_m, net.get_parameter(k).shape, net.get_parameter(k).stride(), o).cpu().contiguous()
+        assert _rel(m_gpu, bufs[k]) < 8e-2, ("momentum", k)
+        checked += 1
+    assert checked >= 40
+    # and the parameters themselves (dominated by their initial values) agree far more tightly
+    for k in names:
+        assert _rel(sd[k], params[k]) < 1e-4, k
+
+
+def test_full_config2_step_is_bitwise_reproducible():
+    """Race check for the two-stream backward (weight gradients on a side stream, model.py _BackboneFn.backward) and the
+    split-K reductions: the full BASELINE configs[1] step (448x448, batch 64, dropout off) run twice from identical
+    state must leave bitwise identical parameters, momentum and bf16 shadow.  A missing event between a side-stream
+    weight gradient and the optimiser, or an order-dependent reduction, shows up as a difference."""
+    assert ym._TWO_STREAMS
+    tnp = synth.v1_targets(64, seed=1)
+    x = torch.rand(64, 3, 448, 448, generator=torch.Generator().manual_seed(0)).to(DEV)
+    tgt = torch.from_numpy(tnp).to(DEV)
+    crit = y.YoloV1Loss(7, 2, 20)
+    outs = []
+    for run in range(2):
+        torch.manual_seed(0)
+        net = ym.YoloRegressorModel(head_out=1470, p_drop=0.0).to(DEV)
+        opt = yt.FlatSGD(net.parameters(), lr=1e-3, momentum=0.9, weight_decay=5e-4, max_norm=1.0)
+        for _ in range(2):
+            opt.zero_grad()
+            crit(net(x), tgt).backward()
+            opt.step()
+        torch.cuda.synchronize()
+        outs.append((opt.flat_p.clone(), opt.flat_m.clone(), opt.flat_p16.clone()))
+        del net, opt
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+def test_enabled_grad_scaler_gives_the_same_step():
+    """train_one_epoch with torch.amp.GradScaler(enabled=True) (what the reference's main() passes, :387): the loss scale
+    (a power of two: exact in bf16 and fp32) must be removed from every gradient, the deferred fc.1 factors included,
+    before the norm and the clip — the trajectory equals the unscaled one."""
+    xs = torch.rand(16, 3, 64, 64, generator=torch.Generator().manual_seed(3))
+    ys = torch.rand(16, 4, generator=torch.Generator().manual_seed(4)) * 0.5 + 0.25
+    loader = [(xs[i:i + 8], ys[i:i + 8]) for i in (0, 8)]
+    res = []
+    for enabled in (False, True):
+        torch.manual_seed(0)
+        net = ym.YoloRegressorModel(head_out=4, image_size=64, p_drop=0.0).to(DEV)
+        # a deferred-capable fc.1 (the full-size model's is; at 64x64 it has 1024 inputs) so the factor path is exercised
+        net.fc[1].weight._yfs_defer_capable = True
+        opt = yt.FlatSGD(net.parameters(), lr=1e-2, momentum=0.9, weight_decay=5e-4)
+        assert net.fc[1].weight._yfs_defer
+        scaler = torch.amp.GradScaler("cuda", enabled=enabled, init_scale=1024.0)
+        losses = [yt.train_one_epoch(net, loader, DEV, opt, scaler, y.MSELoss(), 1.0) for _ in range(2)]
+        res.append((losses, opt.flat_p.clone()))
+        if enabled:
+            assert scaler.get_scale() == 1024.0
+    assert res[0][0] == pytest.approx(res[1][0], rel=1e-5)
+    assert _rel(res[1][1], res[0][1]) < 1e-6
+    # a non-finite gradient skips the step and backs the scale off
+    torch.manual_seed(0)
+    net = ym.YoloRegressorModel(head_out=4, image_size=64, p_drop=0.0).to(DEV)
+    opt = yt.FlatSGD(net.parameters(), lr=1e-2)
+    scaler = torch.amp.GradScaler("cuda", enabled=True, init_scale=1024.0)
+    p0 = opt.flat_p.clone()
+    bad = [(xs[:8], torch.full((8, 4), float("inf")))]
+    yt.train_one_epoch(net, bad, DEV, opt, scaler, y.MSELoss(), 1.0)
+    assert torch.equal(opt.flat_p, p0) and scaler.get_scale() == 512.0
+
+
+def test_backbone_model_under_data_parallel_exchange(monkeypatch):
+    """N > 1 on one GPU for the WHOLE model (Backbone with its weight-gradient stream + fc head with the deferred
+    fc.1): a GradComm of world size 2 whose collectives return what two ranks holding the same data would produce.
+    Small buckets and tail buckets force many exchanges in the middle of backward, issued from the side-stream context
+    (register_producer_stream) as well as from the main stream.  The mean gradient equals the single-process one, so
+    the trajectory must match a run without exchange bit for bit in fp32 mode (x2 then x0.5 is exact)."""
+    from yolo_from_scratch_amd import dp
+    world = 2
+    calls = {"ar": 0, "ag": 0}
+
+    def fake_all_gather(outs, t, group=None):
+        calls["ag"] += 1
+        for o in outs:
+            o.copy_(t)
+
+    def fake_all_reduce(t, op=None, group=None, async_op=False):
+        calls["ar"] += 1
+        t.mul_(world)
+    monkeypatch.setattr(dp.dist, "all_gather", fake_all_gather)
+    monkeypatch.setattr(dp.dist, "all_reduce", fake_all_reduce)
+    x = torch.rand(4, 3, 64, 64, generator=torch.Generator().manual_seed(7)).to(DEV)
+    tgt = torch.from_numpy(synth.v1_targets(4, seed=3)).to(DEV)
+    crit = y.YoloV1Loss(7, 2, 20)
+
+    def run(comm):
+        torch.manual_seed(0)
+        net = ym.YoloRegressorModel(head_out=1470, image_size=64, p_drop=0.0).to(DEV)
+        net.fc[1].weight._yfs_defer_capable = True
+        opt = yt.FlatSGD(net.parameters(), lr=1e-2, momentum=0.9, weight_decay=5e-4, max_norm=1.0, comm=comm)
+        for _ in range(3):
+            opt.zero_grad()
+            crit(net(x), tgt).backward()
+            opt.step()
+        torch.cuda.synchronize()
+        return opt
+    comm = dp.GradComm(world, bucket_bytes=36 << 20, tail_bytes=16 << 20, tail_bucket_bytes=4 << 20)
+    oa = run(comm)
+    assert len(comm.buckets) >= 8 and calls["ar"] == 3 * len(comm.buckets) and calls["ag"] == 3 * 2
+    assert any(e - s < (2 << 20) for s, e in comm.buckets)              # tail buckets present
+    ob = run(None)
+    assert torch.equal(oa.flat_p[: oa.offsets[-4][0]], ob.flat_p[: ob.offsets[-4][0]])     # feat: exact
+    assert _rel(oa.flat_p, ob.flat_p) < 1e-6 and _rel(oa.flat_m, ob.flat_m) < 2e-5       # fc.1: 2B-row fused kernel
+    calls["ar"] = calls["ag"] = 0
+    oc = run(dp.GradComm(world, bucket_bytes=8 << 20, compress_bf16=True))
+    assert _rel(oc.flat_p, ob.flat_p) < 1e-4                                                # bf16 buckets: rounding only

@@ -35,8 +35,11 @@ def out_hw(h, w, k, stride):
 
 
 def workspace(nbytes, device):
-    """Per-device scratch reused across calls on the current stream (caller-owned per the C ABI)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    """Scratch reused across calls, one buffer per (device, current stream): the backward chain runs weight
+    gradients on a second stream, and a buffer shared between streams could be regrown (freed to one stream's pool)
+    or rewritten while a kernel of the other stream still uses it.  Caller-owned per the C ABI."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), device=device, dtype=torch.uint8)
@@ -103,6 +106,34 @@ def weight_prep_batch(items):
             a.Cout, a.K, a.Cin, a.w_is_bf16 = cout, k, cin, s16
         L.check(L.lib().yfs_weight_prep_batch_bf16(arr, L.c_int(len(chunk)), L.stream()), "yfs_weight_prep_batch_bf16")
     return out
+
+
+def fold_batchnorm(bn, conv_bias=None):
+    """(scale, shift) of an eval-mode nn.BatchNorm2d folded behind a convolution: scale = gamma / sqrt(var + eps),
+    shift = beta + (conv_bias - mean) * scale (README.md:30 of the reference names Conv + BN + LeakyReLU as its next
+    block; the snapshot itself has no BatchNorm)."""
+    inv = torch.rsqrt(bn.running_var.detach().float() + bn.eps)
+    gamma = bn.weight.detach().float() if bn.weight is not None else torch.ones_like(inv)
+    beta = bn.bias.detach().float() if bn.bias is not None else torch.zeros_like(inv)
+    scale = gamma * inv
+    b = conv_bias.detach().float() if conv_bias is not None else torch.zeros_like(inv)
+    return scale.contiguous(), (beta + (b - bn.running_mean.detach().float()) * scale).contiguous()
+
+
+def conv_fwd_affine(x, w16, scale, shift, stride=1, slope=0.1):
+    """leaky(conv(x, w) * scale[c] + shift[c]): Conv + folded BatchNorm + LeakyReLU in one launch (scale=None: 1)."""
+    L.require_cuda(x, w16, scale, shift)
+    x = nhwc(x, torch.bfloat16)
+    n, cin, h, w = x.shape
+    cout, cin2, k, _ = w16.shape
+    if cin2 != cin:
+        raise L.YfsError(f"conv_fwd_affine: input has {cin} channels, weight expects {cin2}")
+    oh, ow = out_hw(h, w, k, stride)
+    y = _empty_nhwc(n, cout, oh, ow, x.device)
+    L.check(L.lib().yfs_conv2d_fwd_affine_bf16(L.ptr(x), L.ptr(w16), L.ptr(scale), L.ptr(shift), L.ptr(y), L.i64(n), L.c_int(h),
+                                               L.c_int(w), L.c_int(cin), L.c_int(cout), L.c_int(k), L.c_int(stride),
+                                               L.c_float(slope), L.stream()), "yfs_conv2d_fwd_affine_bf16")
+    return y
 
 
 def conv_fwd(x, w16, bias, stride=1, slope=0.1):

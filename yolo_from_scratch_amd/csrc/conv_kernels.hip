@@ -7,11 +7,13 @@
 //
 //   forward / dgrad ("igemm"): out[pixel][n] = sum_{tap,c} in[gather(pixel,tap)][c] * wt[n][tap][c]
 //     MFMA roles: A operand = weight rows (n), B operand = gathered pixels, so every lane ends up with
-//     4 consecutive output channels of one pixel.  Block tile BM pixels x BN channels x 64 deep, 4 waves
-//     (2x2), operands register-staged (global 16 B -> VGPR -> ds_write_b128, issued one tile ahead so
-//     the loads fly under the MFMAs), LDS rows of 128 B XOR-swizzled by (row & 7) so the fragment
-//     ds_read_b128 is conflict free; epilogue goes through an fp32 LDS tile so bias / LeakyReLU / the
+//     4 consecutive output channels of one pixel.  Operands go global -> LDS directly (buffer_load ... lds,
+//     16 B per lane; conv padding and tile tails are out-of-range offsets that the hardware zero-fills), LDS
+//     rows of 128 B XOR-swizzled by (row & 7) on the SOURCE side so the fragment ds_read_b128 is conflict
+//     free; epilogue goes through an fp32 LDS tile so bias (or folded-BN scale/shift) / LeakyReLU / the
 //     activation-derivative mask run in fp32 and the bf16 result leaves as whole 16 B per lane.
+//     igemm_kernel: BM x BN x 64 tiles, 4 or 8 waves, 2-stage ring; igemm8_kernel: 256 (224) x 256 tiles,
+//     8 waves in two staggered groups, half-tiles staged two K-steps ahead (the long-K 3x3 layers).
 //   wgrad: dw[co][tap][ci] = sum_pixel dz[pixel][co] * x[gather(pixel,tap)][ci] — both operands have the
 //     reduction index (pixel) as the slow axis, so the LDS tiles keep [pixel][channel] rows and the
 //     fragments are read with ds_read_b64_tr_b16 (hardware transpose); split-K over pixels with fp32
@@ -47,7 +49,8 @@ enum { EPI_BIAS_LEAKY = 0, EPI_MASK = 1, EPI_NONE = 2, EPI_POOL = 3 };
 struct IgemmArgs {
     const bf16_t* x;      // [N,H,W,C]
     const bf16_t* w;      // [NOUT][taps][C]
-    const float* bias;    // [NOUT]            (EPI_BIAS_LEAKY)
+    const float* bias;    // [NOUT]            (EPI_BIAS_LEAKY, EPI_POOL)
+    const float* scale;   // [NOUT] or null    (folded BatchNorm: y = leaky(acc * scale + bias); null = 1, the reference's block)
     const bf16_t* act;    // [M][NOUT]         (EPI_MASK: multiply by act > 0 ? 1 : slope)
     unsigned short* pool_idx;   // EPI_POOL: [M/4][NOUT/8] eight 2-bit window positions each; out is then [M/4][NOUT]
     bf16_t* out;          // [M][NOUT]
@@ -280,10 +283,15 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) igemm_kernel(IgemmArgs g) {
     static_assert(PR % 16 == 0 && (!EVEN || PR % RPP == 0), "epilogue slab must hold whole fragments and whole sweeps");
     int ec = (tid % TPR) * 8;
     const int er = tid / TPR;
-    float bv[8];
+    // per-channel scale of a folded BatchNorm: 1 when absent — fma(v, 1, b) == v + b bit for bit, so the reference's
+    // bias-only block needs no second code path
+    float bv[8], sv[8];
     if (EPI == EPI_BIAS_LEAKY && EVEN) {   // (EPI_POOL loads its bias per item below)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bv[j] = g.bias[n0 + ec + j];
+        for (int j = 0; j < 8; ++j) {
+            bv[j] = g.bias[n0 + ec + j];
+            sv[j] = g.scale ? g.scale[n0 + ec + j] : 1.0f;
+        }
     }
 #pragma unroll
     for (int pass = 0; pass < EPASS; ++pass) {
@@ -306,9 +314,12 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) igemm_kernel(IgemmArgs g) {
                 const int w = item / TPR, c8 = item - w * TPR;
                 const int q = ((m0 + pass * PR) >> 2) + w;
                 if (q * 4 >= Mc) continue;
-                float bvp[8];
+                float bvp[8], svp[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) bvp[j] = g.bias[n0 + c8 * 8 + j];
+                for (int j = 0; j < 8; ++j) {
+                    bvp[j] = g.bias[n0 + c8 * 8 + j];
+                    svp[j] = g.scale ? g.scale[n0 + c8 * 8 + j] : 1.0f;
+                }
                 bf16x8 best;
                 unsigned packed = 0;
 #pragma unroll
@@ -319,7 +330,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) igemm_kernel(IgemmArgs g) {
                     const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float t = v[j] + bvp[j];
+                        const float t = __builtin_fmaf(v[j], svp[j], bvp[j]);
                         const bf16_t yv = (bf16_t)(t > 0.0f ? t : t * g.slope);
                         if (k == 0 || (float)yv > (float)best[j]) {
                             best[j] = yv;
@@ -341,7 +352,10 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) igemm_kernel(IgemmArgs g) {
                 ec = (item - row * TPR) * 8;
                 if (EPI == EPI_BIAS_LEAKY) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) bv[j] = g.bias[n0 + ec + j];
+                    for (int j = 0; j < 8; ++j) {
+                        bv[j] = g.bias[n0 + ec + j];
+                        sv[j] = g.scale ? g.scale[n0 + ec + j] : 1.0f;
+                    }
                 }
             }
             int m = m0 + pass * PR + row;
@@ -359,7 +373,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) igemm_kernel(IgemmArgs g) {
             if (EPI == EPI_BIAS_LEAKY) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float t = v[j] + bv[j];
+                    const float t = __builtin_fmaf(v[j], sv[j], bv[j]);
                     v[j] = t > 0.0f ? t : t * g.slope;
                 }
             } else if (EPI == EPI_MASK) {
@@ -432,7 +446,7 @@ int launch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
 constexpr int B8_HALF = 128 * 128;     // one half-tile: 128 rows x 128 B
 constexpr int B8_BUF = 4 * B8_HALF;    // [P0 | P1 | W0 | W1]
 constexpr int B8_LDS = 2 * B8_BUF;
-constexpr int B8_EPI_STRIDE = 256 * 4 + 16, B8_EPI_ROWS = 64;   // epilogue: four slabs of 64 rows through the ring
+constexpr int B8_EPI_STRIDE = 256 * 4 + 16;   // epilogue: four slabs of <= 64 rows of the fp32 tile through the ring
 
 // FP1 = pixel fragments per wave in the SECOND pixel half-tile: 4 -> 256-row tile, 3 -> 224-row tile (P1 holds 96 rows,
 // phases 3 and 4 run 12 MFMAs).  Every GEMM M of this network is 64 * (7 * 2^k)^2, so 224-row tiles have no ragged edge
@@ -633,10 +647,13 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
     // with NF = 4 fragments per wave in the first pixel half and FP1 in the second; slab = one wave row of one half
     constexpr int TPR = BN / 8, RPP = NT / TPR;
     const int ec = (tid % TPR) * 8, er = tid / TPR;
-    float bv[8];
+    float bv[8], sv[8];
     if (EPI == EPI_BIAS_LEAKY) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bv[j] = g.bias[n0 + ec + j];
+        for (int j = 0; j < 8; ++j) {
+            bv[j] = g.bias[n0 + ec + j];
+            sv[j] = g.scale ? g.scale[n0 + ec + j] : 1.0f;
+        }
     }
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
@@ -663,9 +680,12 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
             const int w = tid / TPR, c8 = tid - w * TPR;
             const int q = ((m0 + rbase) >> 2) + w;
             if (w < PR / 4 && q * 4 < Mc) {
-                float bvp[8];
+                float bvp[8], svp[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) bvp[j] = g.bias[n0 + c8 * 8 + j];
+                for (int j = 0; j < 8; ++j) {
+                    bvp[j] = g.bias[n0 + c8 * 8 + j];
+                    svp[j] = g.scale ? g.scale[n0 + c8 * 8 + j] : 1.0f;
+                }
                 bf16x8 best;
                 unsigned packed = 0;
 #pragma unroll
@@ -676,7 +696,7 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
                     const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float tv = v[j] + bvp[j];
+                        const float tv = __builtin_fmaf(v[j], svp[j], bvp[j]);
                         const bf16_t yv = (bf16_t)(tv > 0.0f ? tv : tv * g.slope);
                         if (k == 0 || (float)yv > (float)best[j]) {
                             best[j] = yv;
@@ -701,7 +721,7 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
                 if (EPI == EPI_BIAS_LEAKY) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float tv = v[j] + bv[j];
+                        const float tv = __builtin_fmaf(v[j], sv[j], bv[j]);
                         v[j] = tv > 0.0f ? tv : tv * g.slope;
                     }
                 } else if (EPI == EPI_MASK) {
@@ -815,20 +835,26 @@ int check_conv_shape(const char* fn, int64_t N, int H, int W, int Cin, int Cout,
 
 }  // namespace
 
-YFS_API int yfs_conv2d_fwd_bf16(const void* x, const void* w, const float* bias, void* y, int64_t N, int H, int W,
-                                int Cin, int Cout, int K, int stride, float slope, void* stream) {
-    YFS_REQUIRE(x && w && bias && y, YFS_ERR_INVALID_ARG, "yfs_conv2d_fwd_bf16: null pointer");
-    int rc = check_conv_shape("yfs_conv2d_fwd_bf16", N, H, W, Cin, Cout, K, stride);
+YFS_API int yfs_conv2d_fwd_affine_bf16(const void* x, const void* w, const float* scale, const float* shift, void* y, int64_t N,
+                                       int H, int W, int Cin, int Cout, int K, int stride, float slope, void* stream) {
+    YFS_REQUIRE(x && w && shift && y, YFS_ERR_INVALID_ARG, "yfs_conv2d_fwd_affine_bf16: null pointer");
+    int rc = check_conv_shape("yfs_conv2d_fwd_affine_bf16", N, H, W, Cin, Cout, K, stride);
     if (rc) return rc;
     const int pad = K / 2;
     IgemmArgs g = {};
-    g.x = (const bf16_t*)x; g.w = (const bf16_t*)w; g.bias = bias; g.out = (bf16_t*)y;
+    g.x = (const bf16_t*)x; g.w = (const bf16_t*)w; g.bias = shift; g.scale = scale; g.out = (bf16_t*)y;
     g.N = (int)N; g.H = H; g.W = W; g.C = Cin;
     g.OH = (H + 2 * pad - K) / stride + 1; g.OW = (W + 2 * pad - K) / stride + 1; g.NOUT = Cout;
     g.KH = g.KW = K; g.PS = Cin; g.s_mul = stride; g.pad = pad; g.slope = slope;
     g.M = (int)(N * g.OH * g.OW);
     g.xbytes = (unsigned)(N * H * W * Cin * 2); g.wbytes = (unsigned)((int64_t)Cout * K * K * Cin * 2);
-    return dispatch_igemm<EPI_BIAS_LEAKY, false>(g, (hipStream_t)stream, "yfs_conv2d_fwd_bf16");
+    return dispatch_igemm<EPI_BIAS_LEAKY, false>(g, (hipStream_t)stream, "yfs_conv2d_fwd_affine_bf16");
+}
+
+YFS_API int yfs_conv2d_fwd_bf16(const void* x, const void* w, const float* bias, void* y, int64_t N, int H, int W,
+                                int Cin, int Cout, int K, int stride, float slope, void* stream) {
+    YFS_REQUIRE(x && w && bias && y, YFS_ERR_INVALID_ARG, "yfs_conv2d_fwd_bf16: null pointer");
+    return yfs_conv2d_fwd_affine_bf16(x, w, nullptr, bias, y, N, H, W, Cin, Cout, K, stride, slope, stream);
 }
 
 YFS_API int yfs_conv2d_fwd_pool_bf16(const void* x, const void* w, const float* bias, void* y_pooled, void* pool_idx, int64_t N,

@@ -48,6 +48,7 @@ class GradComm:
         self.stream = None
         self._issued = []
         self._c16 = None
+        self._host_waits = []      # (work, chunk) of collectives whose completion the host must wait for (gloo)
 
     # -- layout -----------------------------------------------------------------------------------
     def attach(self, params, offsets, flat_g, skip_ids=()):
@@ -104,12 +105,25 @@ class GradComm:
             self._issue(idx)
 
     def _issue(self, idx):
+        """Start bucket idx's all-reduce.  Called from the autograd thread in the middle of backward, so it must never
+        wait on the HOST for a peer: a rank that blocked here could not enqueue the rest of its backward, and on a
+        backend whose collectives are host-synchronous (gloo) two ranks would serialise on every bucket (round 1's
+        one-GPU gloo rehearsal ended in exactly such a wait, gpurun_out/dp2.log).  Every collective is therefore
+        started with async_op=True:
+          * nccl (= RCCL): the collective is enqueued on RCCL's own stream behind the exchange stream; ``work.wait()``
+            only makes the exchange stream wait for it (a stream dependency, no host block), and the 1/world scale is
+            queued behind it;
+          * gloo (CPU tensors in tests, CUDA tensors in rehearsals): the Work object is kept and ``reduce`` — called by
+            FlatSGD.step after backward has been enqueued completely — waits for it and applies the scale.
+        Order: a bucket is issued when its last parameter reports, and ``reduce`` issues the rest in index order; both are
+        functions of the autograd graph alone, which is identical on every rank, so all ranks issue the same sequence."""
         self._issued[idx] = True
         lo, hi = self.buckets[idx]
         chunk = self.flat[lo:hi]
-        if self.stream is None:                               # CPU / gloo (tests)
-            dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
-            chunk.mul_(1.0 / self.world)
+        host_sync = dist.is_initialized() and dist.get_backend(self.group) != "nccl"
+        if self.stream is None:                               # CPU tensors (gloo tests)
+            work = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._host_waits.append((work, chunk, None))
             return
         cur = torch.cuda.current_stream()
         evs = []
@@ -120,13 +134,26 @@ class GradComm:
         with torch.cuda.stream(self.stream):
             for ev in evs:
                 self.stream.wait_event(ev)
+            buf = chunk
             if self.compress:
-                c = self._c16[: hi - lo]
-                c.copy_(chunk)
-                dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group)
-                torch.mul(c, 1.0 / self.world, out=chunk)
+                # one staging buffer for all buckets: safe because every use is ordered on the exchange stream
+                buf = self._c16[: hi - lo]
+                buf.copy_(chunk)
+            if host_sync:
+                if self.compress:
+                    buf = chunk.to(torch.bfloat16)            # several host-side collectives in flight: own staging each
+                # gloo reads the tensor from the host side: the producing kernels must have finished first; this wait
+                # is on this rank's own GPU work only, never on a peer
+                self.stream.synchronize()
+                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._host_waits.append((work, chunk, buf if self.compress else None))
+                return
+            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if work is not None:
+                work.wait()                                   # nccl: stream-level wait on the exchange stream
+            if self.compress:
+                torch.mul(buf, 1.0 / self.world, out=chunk)
             else:
-                dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
                 chunk.mul_(1.0 / self.world)
 
     def gather_factors(self, x16, dy16):
@@ -163,6 +190,18 @@ class GradComm:
             for idx in range(len(self.buckets)):
                 if not self._issued[idx]:
                     self._issue(idx)
+            for work, chunk, staged in self._host_waits:      # gloo only: backward is fully enqueued by now
+                if work is not None:
+                    work.wait()
+                if self.stream is not None:
+                    with torch.cuda.stream(self.stream):
+                        if staged is not None:
+                            torch.mul(staged, 1.0 / self.world, out=chunk)
+                        else:
+                            chunk.mul_(1.0 / self.world)
+                else:
+                    chunk.mul_(1.0 / self.world)
+            self._host_waits = []
             if self.stream is not None:
                 torch.cuda.current_stream().wait_stream(self.stream)
         self.begin_step()

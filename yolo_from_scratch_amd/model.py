@@ -581,8 +581,3 @@ class YoloRegressorModel(nn.Module):
         x = self.feat(x)
         # the reference flattens NCHW; x is NHWC in memory, so flatten() permutes (6 MB at batch 64)
         return self.fc(x).float()
-
-
-def load_reference_state_dict(model, state_dict):
-    """Load a checkpoint written by the reference (contiguous NCHW weights); layouts are converted by copy_."""
-    return model.load_state_dict(state_dict)

@@ -107,7 +107,7 @@ def fit(model, train_loader, val_loader, device, opt, loss_fn, *, total_epochs=1
         if torch.cuda.is_available():
             torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        seen = sum(int(xb.shape[0]) for xb, _ in train_loader) if hasattr(train_loader, "__len__") else 0
+        seen = getattr(train_one_epoch, "last_count", 0)      # images the epoch just consumed (the loader is not re-iterated)
         ips = seen / dt if dt > 0 else 0.0
         val_loss, val_iou = evaluate(model, val_loader, device, loss_fn)
         if verbose:

@@ -161,7 +161,7 @@ class FlatSGD(torch.optim.Optimizer):
         L.check(L.lib().yfs_sumsq_f32(L.ptr(self.flat_g[lo:hi]), L.i64(n), L.ptr(out), L.ptr(self._ws), L.c_size(self._ws_bytes),
                                       L.stream()), "yfs_sumsq_f32")
 
-    def _step_with_deferred(self, deferred, max_norm):
+    def _step_with_deferred(self, deferred, max_norm, need_norm=False):
         """Parameters in ``deferred`` carry (x16, dy16) instead of a gradient.  Norm: materialised ranges by the
         sumsq kernel, deferred ones as ||dy^T x||_F^2 = sum((dy dy^T) * (x x^T)); then the plain SGD kernel over the
         materialised ranges and the fused wgrad + SGD kernel per deferred parameter."""
@@ -176,7 +176,7 @@ class FlatSGD(torch.optim.Optimizer):
         if lo < self.total:
             ranges.append((lo, self.total))
         sumsq = None
-        if max_norm is not None and max_norm > 0:
+        if need_norm or (max_norm is not None and max_norm > 0):
             parts = torch.zeros(len(ranges) + len(deferred), device=self.flat_g.device, dtype=torch.float32)
             for i, (a, b) in enumerate(ranges):
                 self._sumsq_range(a, b, parts[i:i + 1])
@@ -187,6 +187,12 @@ class FlatSGD(torch.optim.Optimizer):
                 parts[len(ranges) + j] = (gx * gy).sum() * (gs * gs)
             torch.sum(parts, dim=0, keepdim=True, out=self._sumsq)
             sumsq = self._sumsq
+            if need_norm and not bool(torch.isfinite(self._sumsq).item()):     # GradScaler semantics: skip the step
+                for p in deferred:
+                    p._yfs_factors = None
+                return False
+            if not (max_norm is not None and max_norm > 0):
+                sumsq = None
         first = L.c_int(1 if self._first else 0)
         for a, b in ranges:
             L.check(L.lib().yfs_sgd_step_f32(L.ptr(self.flat_p[a:b]), L.ptr(self.flat_g[a:b]), L.ptr(self.flat_m[a:b]), L.i64(b - a),
@@ -202,27 +208,44 @@ class FlatSGD(torch.optim.Optimizer):
                                 self._first, gs)
             p._yfs_factors = None
         self._first = False
+        return True
 
     @torch.no_grad()
-    def step(self, closure=None, max_norm="default"):
+    def step(self, closure=None, max_norm="default", grad_scale=None):
+        """``grad_scale`` (GradScaler path, train_one_epoch): every gradient of this step carries the loss scale
+        1/grad_scale; it is removed here — from the materialised gradients in place and from the factors of a deferred
+        Linear weight through the fused kernel's own scale — AFTER the data-parallel exchange and BEFORE the norm, so
+        clipping sees the true averaged gradient.  Returns False (and leaves the parameters untouched) when that
+        gradient is not finite, which is what torch.amp.GradScaler.step does; True otherwise."""
         if max_norm == "default":
             max_norm = self.max_norm
         self._finish_grads()
         if self.comm is not None:
             self.comm.reduce(self.flat_g)
         deferred = [p for p in self._params if getattr(p, "_yfs_factors", None) is not None]
+        check = grad_scale is not None
+        if check and grad_scale != 1.0:
+            self.flat_g.mul_(grad_scale)
+            for p in deferred:
+                x16, dy16, gs = p._yfs_factors
+                p._yfs_factors = (x16, dy16, gs * grad_scale)
         if deferred:
-            return self._step_with_deferred(deferred, max_norm)
+            return self._step_with_deferred(deferred, max_norm, need_norm=check)
         g = self.param_groups[0]
         sumsq = None
-        if max_norm is not None and max_norm > 0:
+        if check or (max_norm is not None and max_norm > 0):
             sumsq = self.grad_norm()
+            if check and not bool(torch.isfinite(sumsq).item()):
+                return False
+            if not (max_norm is not None and max_norm > 0):
+                sumsq = None
         L.check(L.lib().yfs_sgd_step_f32(L.ptr(self.flat_p), L.ptr(self.flat_g), L.ptr(self.flat_m), L.i64(self.total),
                                          L.ptr(sumsq), L.c_float(max_norm or 0.0), L.c_float(g["lr"]),
                                          L.c_float(g["momentum"]), L.c_float(g["weight_decay"]),
                                          L.c_int(1 if self._first else 0), L.ptr(self.flat_p16), L.stream()),
                 "yfs_sgd_step_f32")
         self._first = False
+        return True
 
 
 def bf16_shadow(param):
@@ -278,7 +301,10 @@ def evaluate(model, loader, device, loss_fn):
 # ---- yolo_toy_regressor_torch.py:314-339 --------------------------------------------------------
 def train_one_epoch(model, loader, device, opt, scaler, loss_fn, max_norm=1.0):
     """Same call and return as the reference.  The model computes in bf16 internally, so ``scaler`` may be a
-    disabled GradScaler (or None); an enabled one still works (bf16 has fp32's exponent range)."""
+    disabled GradScaler (or None).  An enabled one works too: with FlatSGD the loss scale is removed inside
+    ``opt.step`` (after the data-parallel exchange, before the norm and the clip, deferred Linear factors included),
+    a non-finite gradient skips the step and halves the scale as GradScaler does; the scale is never grown (bf16 has
+    fp32's exponent range, growth buys nothing).  With any other optimiser the reference's own sequence runs."""
     model.train()
     # The reference adds loss.item() every batch (:337), which stalls the host on the stream each step; the same
     # sum is kept on the device in fp64 (what the Python float sum is) and read once at the end of the epoch.
@@ -286,30 +312,40 @@ def train_one_epoch(model, loader, device, opt, scaler, loss_fn, max_norm=1.0):
     n = 0
     flat = isinstance(opt, FlatSGD)
     # A generation-2 garbage collection walks every object torch created at import (~75 ms) while the GPU idles;
-    # freezing what exists now keeps later full collections to the few objects the loop itself creates.
+    # freezing what exists now keeps full collections during the epoch to the few objects the loop itself creates.
+    # The caller's heap is thawed again before returning.
     gc.collect()
     gc.freeze()
-    for xb, yb in loader:
-        xb = xb.to(device, non_blocking=True)
-        yb = yb.to(device, non_blocking=True)
-        opt.zero_grad(set_to_none=True)
-        preds = model(xb)
-        loss = loss_fn(preds, yb)
-        if scaler is not None and scaler.is_enabled():
-            scaler.scale(loss).backward()
-            scaler.unscale_(opt)
-            if max_norm is not None:
-                nn.utils.clip_grad_norm_(model.parameters(), max_norm)
-            scaler.step(opt, max_norm=None) if flat else scaler.step(opt)
-            scaler.update()
-        else:
-            loss.backward()
-            if flat:
-                opt.step(max_norm=max_norm)
+    try:
+        for xb, yb in loader:
+            xb = xb.to(device, non_blocking=True)
+            yb = yb.to(device, non_blocking=True)
+            opt.zero_grad(set_to_none=True)
+            preds = model(xb)
+            loss = loss_fn(preds, yb)
+            if scaler is not None and scaler.is_enabled():
+                scaler.scale(loss).backward()
+                if flat:
+                    scale = float(scaler.get_scale())
+                    ok = opt.step(max_norm=max_norm, grad_scale=1.0 / scale)
+                    scaler.update(scale if ok else scale * scaler.get_backoff_factor())
+                else:
+                    scaler.unscale_(opt)
+                    if max_norm is not None:
+                        nn.utils.clip_grad_norm_(model.parameters(), max_norm)
+                    scaler.step(opt)
+                    scaler.update()
             else:
-                if max_norm is not None:
-                    nn.utils.clip_grad_norm_(model.parameters(), max_norm)
-                opt.step()
-        running += loss.detach().double() * xb.size(0)
-        n += xb.size(0)
+                loss.backward()
+                if flat:
+                    opt.step(max_norm=max_norm)
+                else:
+                    if max_norm is not None:
+                        nn.utils.clip_grad_norm_(model.parameters(), max_norm)
+                    opt.step()
+            running += loss.detach().double() * xb.size(0)
+            n += xb.size(0)
+    finally:
+        gc.unfreeze()
+    train_one_epoch.last_count = n
     return running.item() / n
