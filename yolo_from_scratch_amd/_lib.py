@@ -6,7 +6,8 @@ import os
 import torch  # noqa: F401  (must be imported first: libyfs.so binds to the HIP runtime torch loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libyfs.so")
+# YFS_LIB_PATH: load another build of the same ABI (A/B measurements of two builds on one GPU box)
+LIB_PATH = os.environ.get("YFS_LIB_PATH") or os.path.join(_HERE, "libyfs.so")
 _lib = None
 
 

@@ -434,14 +434,14 @@ int launch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
 // registers), and the two wave rows run one barrier apart: while waves 0-3 multiply (16 MFMAs between two barriers),
 // waves 4-7 — their partners on the same four SIMDs — read fragments and issue the next LDS-DMA, and vice versa, so
 // the matrix pipe of every SIMD always has one wave feeding it.
-//   phase 1: read W0, P0 fragments | stage W0 of K-step t+1 | MFMA quadrant (P0, W0)
-//   phase 2: read W1               | stage P0 of K-step t+2 | MFMA (P0, W1)
-//   phase 3: read P1               | stage W1 of K-step t+2 | MFMA (P1, W1)
-//   phase 4: read W0 again         | stage P1 of K-step t+2 | MFMA (P1, W0)   + the only vmcnt wait of the K-step
-// A half-tile is restaged one phase after its last read (every wave retires its reads with lgkmcnt(0) BEFORE the
-// phase's first barrier, so the fragments are in registers when the partner group may issue the DMA), i.e. the loads
+//   phase 1: read W0, P0 fragments | stage P1 of tile t+1 | MFMA quadrant (P0, W0)
+//   phase 2: read W1               | stage W0 of tile t+2 | MFMA (P0, W1)
+//   phase 3: read P1               | stage P0 of tile t+2 | MFMA (P1, W1)
+//   phase 4: (W0 stays in regs)    | stage W1 of tile t+2 | MFMA (P1, W0)   + the only vmcnt wait of the K-step
+// A half-tile is restaged as soon as its fragments are in registers (>= 2 phases after it was read; W0 one phase
+// after, which is why every wave retires its reads with lgkmcnt(0) BEFORE the phase's first barrier), i.e. the loads
 // run two K-steps ahead with two buffers.  vmcnt(6) in phase 4 leaves the three half-tiles issued in phases 2-4 in
-// flight (2 LDS-DMA instructions per wave and half-tile) and retires everything older = all of K-step t+1, which is
+// flight (2 LDS-DMA instructions per wave and half-tile) and retires everything older = all of tile t+1, which is
 // first read two barriers later.  Barriers are raw s_barrier (a __syncthreads() would drain the DMA queue).
 constexpr int B8_HALF = 128 * 128;     // one half-tile: 128 rows x 128 B
 constexpr int B8_BUF = 4 * B8_HALF;    // [P0 | P1 | W0 | W1]
@@ -451,42 +451,58 @@ constexpr int B8_EPI_STRIDE = 256 * 4 + 16;   // epilogue: four slabs of <= 64 r
 // FP1 = pixel fragments per wave in the SECOND pixel half-tile: 4 -> 256-row tile, 3 -> 224-row tile (P1 holds 96 rows,
 // phases 3 and 4 run 12 MFMAs).  Every GEMM M of this network is 64 * (7 * 2^k)^2, so 224-row tiles have no ragged edge
 // and their counts (224, 448, 896, ...) fill 256 CUs to 87.5-100 % where 196 / 392 / 784 tiles of 256 rows fill 76.6 %.
-//
-// Persistent: the grid is at most one workgroup per CU and a workgroup walks tiles w, w + G, w + 2G, ...  What that
-// buys is the turn-over between tiles: the next tile's coordinates are computed and its first K-step (and bias / scale
-// rows) is already on its way into buffer 0 while the finished tile's epilogue runs out of buffer 1, so neither the
-// workgroup launch nor the cold first loads sit between two main loops (they cost ~4 us of the ~12 us a round of 256
-// one-tile workgroups paid on top of its main loop).  vmcnt counts stores too, in order: the epilogue therefore waits
-// for those early loads BEFORE it issues its first store (cheap: nothing else is outstanding), and the first counted
-// wait of the next main loop, one K-step later, is the only place where the output stores are waited for.
-constexpr int B8_EPI_OFF = B8_BUF;                        // epilogue slabs live in buffer 1 (+ 1 KiB of overflow)
-constexpr int B8_BIAS_OFF = 2 * B8_BUF + 1024;            // [parity][bias 1 KiB | scale 1 KiB]
-constexpr int B8_LDS_P = B8_BIAS_OFF + 2 * 2048;
 template <int EPI, int FP1>
 __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
     constexpr int BM = 128 + FP1 * 32, BN = 256, NT = 512;
-    constexpr bool HAS_BIAS = EPI == EPI_BIAS_LEAKY || EPI == EPI_POOL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __attribute__((address_space(3))) void* lds_ptr;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    const int G = (int)gridDim.x, T = g.mtiles * g.ntiles;
+    const int logical = xcd_remap(blockIdx.x, g.mtiles * g.ntiles);
+    const int nt = logical % g.ntiles, mt = logical / g.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
     const int Mc = g.M, OHc = g.OH, OWc = g.OW;
 
     // ---- staging coordinates: 4 pixel rows and 4 weight rows per thread (2 per half-tile) -----------------------------
     const int chunk = (lane & 7) ^ (lane >> 3);   // source-side XOR swizzle (see igemm_kernel)
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.x, g.xbytes), rw = make_rsrc(g.w, g.wbytes);
-    const __amdgpu_buffer_rsrc_t rb = make_rsrc(HAS_BIAS ? (const void*)g.bias : (const void*)g.w, HAS_BIAS ? (unsigned)g.NOUT * 4u : 0u);
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc((HAS_BIAS && g.scale) ? (const void*)g.scale : (const void*)g.w,
-                                                (HAS_BIAS && g.scale) ? (unsigned)g.NOUT * 4u : 0u);
+    int bh[4], bw[4];
+    unsigned rowbyte[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {   // j = half * 2 + i: tile row half*128 + wave*16 + i*8 + (lane >> 3)
+        const int hr = wave * 16 + (j & 1) * 8 + (lane >> 3);   // row inside the half-tile
+        const int m = m0 + (j >> 1) * 128 + hr;
+        if (m < Mc && (j < 2 || hr < FP1 * 32)) {
+            int n, oh, ow;
+            if (EPI == EPI_POOL) {   // window-major row order (see igemm_kernel)
+                const int q = m >> 2, sub = m & 3, PW = OWc >> 1, PHW = (OHc >> 1) * PW;
+                n = q / PHW;
+                const int r = q - n * PHW;
+                const int py = r / PW, px = r - py * PW;
+                oh = 2 * py + (sub >> 1);
+                ow = 2 * px + (sub & 1);
+            } else {
+                n = m / (OHc * OWc);
+                const int rem = m - n * (OHc * OWc);
+                oh = rem / OWc;
+                ow = rem - oh * OWc;
+            }
+            bh[j] = oh * g.s_mul - g.pad;
+            bw[j] = ow * g.s_mul - g.pad;
+            rowbyte[j] = (unsigned)(((long long)(n * g.H + bh[j]) * g.W + bw[j]) * g.PS * 2) + chunk * 16;
+        } else {
+            bh[j] = -(1 << 28);
+            bw[j] = -(1 << 28);
+            rowbyte[j] = 0;
+        }
+    }
     const unsigned ktot = (unsigned)(g.KH * g.KW * g.C);
+    const unsigned wrow = (unsigned)(n0 + wave * 16 + (lane >> 3)) * ktot * 2 + chunk * 16;
     const int cchunks = g.C / BK;
     const int nit = g.KH * g.KW * cchunks;
-    int m0 = 0, n0 = 0;
-    int bh[4], bw[4];
-    unsigned rowbyte[4], wrow = 0;
-    // position of the K-step the staging state describes: ts = (kh, kw, cc); xoff = this thread's source offsets
+
+    // position of the tile the staging state describes: tile ts = (kh, kw, cc); xoff = this thread's source offsets
     // for that tap (recomputed when the tap changes)
     int kh = 0, kw = 0, cc = 0, ts = 0;
     unsigned xoff[4];
@@ -517,70 +533,22 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
                                                      off, so, 0, 0);
         }
     };
-    auto stage_W = [&](int h, int buf, int k) {   // weight half h of K-step k (the weight row is contiguous over all taps)
+    auto stage_W = [&](int h, int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const unsigned so = ((unsigned)(h * 128 + i * 8) * ktot + (unsigned)k * BK) * 2;
+            const unsigned so = ((unsigned)(h * 128 + i * 8) * ktot + (unsigned)ts * BK) * 2;
             const unsigned off = wrow;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(smem + buf * B8_BUF + (2 + h) * B8_HALF + (wave * 2 + i) * 1024),
                                                      16, off, so, 0, 0);
         }
     };
-    // coordinates of tile `tile`, its bias / scale rows and its first K-step (buffer 0) on their way
-    auto setup_tile = [&](int tile, int par) {
-        const int nt = tile % g.ntiles, mt = tile / g.ntiles;
-        m0 = mt * BM;
-        n0 = nt * BN;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {   // j = half * 2 + i: tile row half*128 + wave*16 + i*8 + (lane >> 3)
-            const int hr = wave * 16 + (j & 1) * 8 + (lane >> 3);   // row inside the half-tile
-            const int m = m0 + (j >> 1) * 128 + hr;
-            if (m < Mc && (j < 2 || hr < FP1 * 32)) {
-                int n, oh, ow;
-                if (EPI == EPI_POOL) {   // window-major row order (see igemm_kernel)
-                    const int q = m >> 2, sub = m & 3, PW = OWc >> 1, PHW = (OHc >> 1) * PW;
-                    n = q / PHW;
-                    const int r = q - n * PHW;
-                    const int py = r / PW, px = r - py * PW;
-                    oh = 2 * py + (sub >> 1);
-                    ow = 2 * px + (sub & 1);
-                } else {
-                    n = m / (OHc * OWc);
-                    const int rem = m - n * (OHc * OWc);
-                    oh = rem / OWc;
-                    ow = rem - oh * OWc;
-                }
-                bh[j] = oh * g.s_mul - g.pad;
-                bw[j] = ow * g.s_mul - g.pad;
-                rowbyte[j] = (unsigned)(((long long)(n * g.H + bh[j]) * g.W + bw[j]) * g.PS * 2) + chunk * 16;
-            } else {
-                bh[j] = -(1 << 28);
-                bw[j] = -(1 << 28);
-                rowbyte[j] = 0;
-            }
-        }
-        wrow = (unsigned)(n0 + wave * 16 + (lane >> 3)) * ktot * 2 + chunk * 16;
-        kh = kw = cc = ts = 0;
-        tap_offsets();
-        if (HAS_BIAS && wave < 2) {   // 256 floats = one wave-instruction each; older than every K-step load of the tile
-            const unsigned off = (unsigned)(n0 * 4 + lane * 16);
-            if (wave == 0)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(smem + B8_BIAS_OFF + par * 2048), 16, off, 0, 0, 0);
-            else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(smem + B8_BIAS_OFF + par * 2048 + 1024), 16, off, 0, 0, 0);
-        }
-        stage_W(0, 0, 0); stage_P(0, 0); stage_W(1, 0, 0); stage_P(1, 0);
-    };
-    auto stage_k1 = [&]() {   // P0 / W1 / P1 of the second K-step -> buffer 1 (W0 follows in phase 1 of the first)
-        if (nit > 1) {
-            advance();
-            stage_P(0, 1); stage_W(1, 1, 1); stage_P(1, 1);
-        }
-    };
 
     f32x4 acc[2][2][2][4];   // [pixel half][weight half][channel fragment][pixel fragment]
+#pragma unroll
+    for (int i = 0; i < 32; ++i) (&acc[0][0][0][0])[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
     const int frow = lane & 15, fk = lane >> 4;
-    bf16x8 pf[4][2], wf[2][2];   // (W0 is read again in phase 4 rather than kept: 16 registers)
+    bf16x8 pf[4][2], w0f[2][2], w1f[2][2];
     auto read_P = [&](const unsigned char* hb, auto nf_tag) {   // nf_tag: fragments per wave in this half (4 or FP1)
         constexpr int NF = decltype(nf_tag)::value;
 #pragma unroll
@@ -589,14 +557,14 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
             for (int ks = 0; ks < 2; ++ks)
                 pf[b][ks] = *reinterpret_cast<const bf16x8*>(hb + swz(wm * (NF * 16) + b * 16 + frow, ks * 4 + fk));
     };
-    auto read_W = [&](const unsigned char* hb) {
+    auto read_W = [&](const unsigned char* hb, bf16x8 (&wf)[2][2]) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
                 wf[a][ks] = *reinterpret_cast<const bf16x8*>(hb + swz(wn * 32 + a * 16 + frow, ks * 4 + fk));
     };
-    auto mfma16 = [&](f32x4 (&c)[2][4], auto nf_tag) {
+    auto mfma16 = [&](f32x4 (&c)[2][4], const bf16x8 (&wf)[2][2], auto nf_tag) {
         constexpr int NF = decltype(nf_tag)::value;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -614,189 +582,161 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
         __builtin_amdgcn_sched_barrier(0);
     };
 
+    // prologue: tile 0 complete, W0 / P0 / W1 of tile 1 in flight (the steady state at the top of a K-step)
+    tap_offsets();
+    stage_W(0, 0); stage_P(0, 0); stage_W(1, 0); stage_P(1, 0);
+    if (nit > 1) {
+        advance();
+        stage_W(0, 1); stage_P(0, 1); stage_W(1, 1);
+        wait_vmcnt<6>();
+    } else {
+        wait_vmcnt<0>();
+    }
+    bar();
+    if (wm == 1) bar();   // waves 4-7 run one barrier behind waves 0-3 from here on
+
     const std::integral_constant<int, 4> F4;
     const std::integral_constant<int, FP1> F1;
-    // phases (W0 is read twice, so every half-tile is restaged exactly one phase after its last read, which the
-    // lgkmcnt(0) in front of that phase's first barrier has retired):
-    //   1: read W0, P0 | stage W0 of K-step t+1 | MFMA (P0, W0)      3: read P1 | stage W1 of t+2 | MFMA (P1, W1)
-    //   2: read W1     | stage P0 of K-step t+2 | MFMA (P0, W1)      4: read W0 | stage P1 of t+2, vmcnt(6) | MFMA (P1, W0)
-    auto kstep = [&](int t, auto buf_tag) {
+    auto tile = [&](int t, auto buf_tag) {
         constexpr int BUF = decltype(buf_tag)::value;
         const unsigned char* tb = smem + BUF * B8_BUF;
         // phase 1
-        read_W(tb + 2 * B8_HALF);
+        read_W(tb + 2 * B8_HALF, w0f);
         read_P(tb, F4);
-        if (t + 1 < nit) stage_W(0, BUF ^ 1, t + 1);
+        if (t + 1 < nit) stage_P(1, BUF ^ 1);
         lgkm0();
         bar();
-        mfma16(acc[0][0], F4);
+        mfma16(acc[0][0], w0f, F4);
         bar();
         // phase 2
-        read_W(tb + 3 * B8_HALF);
-        advance();                       // staging state: K-step t + 2
-        if (ts < nit) stage_P(0, BUF);
+        read_W(tb + 3 * B8_HALF, w1f);
+        advance();
+        if (ts < nit) stage_W(0, BUF);
         lgkm0();
         bar();
-        mfma16(acc[0][1], F4);
+        mfma16(acc[0][1], w1f, F4);
         bar();
         // phase 3
         read_P(tb + B8_HALF, F1);
-        if (ts < nit) stage_W(1, BUF, ts);
+        if (ts < nit) stage_P(0, BUF);
         lgkm0();
         bar();
-        mfma16(acc[1][1], F1);
+        mfma16(acc[1][1], w1f, F1);
         bar();
         // phase 4
-        read_W(tb + 2 * B8_HALF);
         if (ts < nit) {
-            stage_P(1, BUF);
+            stage_W(1, BUF);
             wait_vmcnt<6>();
         } else {
             wait_vmcnt<0>();
         }
-        lgkm0();
         bar();
-        mfma16(acc[1][0], F1);
+        mfma16(acc[1][0], w0f, F1);
         bar();
     };
+    int t = 0;
+    for (; t + 1 < nit; t += 2) {
+        tile(t, std::integral_constant<int, 0>());
+        tile(t + 1, std::integral_constant<int, 1>());
+    }
+    if (t < nit) tile(t, std::integral_constant<int, 0>());
+    if (wm == 0) bar();   // catch up with waves 4-7: every wave is past its last fragment read after this
 
-    int tile = xcd_remap(blockIdx.x, G), par = 0;
-    // first tile: K-step 0 complete, P0 / W1 / P1 of K-step 1 in flight (the steady state at the top of a K-step)
-    setup_tile(tile, par);
-    stage_k1();
-    if (nit > 1) wait_vmcnt<6>(); else wait_vmcnt<0>();
-    bar();
-    for (;;) {
+    // ---- epilogue: four 64-row slabs of the fp32 tile through LDS, then coalesced 16 B stores (as igemm_kernel) ----
+    // acc[ph][wh][a][b][r] = out[pixel ph*128 + wm*NF*16 + b*16 + (lane&15)][chan wh*128 + wn*32 + a*16 + (lane>>4)*4 + r]
+    // with NF = 4 fragments per wave in the first pixel half and FP1 in the second; slab = one wave row of one half
+    constexpr int TPR = BN / 8, RPP = NT / TPR;
+    const int ec = (tid % TPR) * 8, er = tid / TPR;
+    float bv[8], sv[8];
+    if (EPI == EPI_BIAS_LEAKY) {
 #pragma unroll
-        for (int i = 0; i < 32; ++i) (&acc[0][0][0][0])[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (wm == 1) bar();   // waves 4-7 run one barrier behind waves 0-3 from here on
-        int t = 0;
-        for (; t + 1 < nit; t += 2) {
-            kstep(t, std::integral_constant<int, 0>());
-            kstep(t + 1, std::integral_constant<int, 1>());
+        for (int j = 0; j < 8; ++j) {
+            bv[j] = g.bias[n0 + ec + j];
+            sv[j] = g.scale ? g.scale[n0 + ec + j] : 1.0f;
         }
-        if (t < nit) kstep(t, std::integral_constant<int, 0>());
-        if (wm == 0) bar();   // catch up with waves 4-7: every wave is past its last fragment read after this
-
-        const int em0 = m0, en0 = n0, epar = par;
-        const int next = tile + G;
-        if (next < T) setup_tile(next, par ^ 1);   // overwrites the staging state; buffer 0 and the other bias slot
-
-        // ---- epilogue: four slabs of the fp32 tile through buffer 1, then coalesced 16 B stores (as igemm_kernel) ----
-        // acc[ph][wh][a][b][r] = out[pixel ph*128 + wm*NF*16 + b*16 + (lane&15)][chan wh*128 + wn*32 + a*16 + (lane>>4)*4 + r]
-        // with NF = 4 fragments per wave in the first pixel half and FP1 in the second; slab = one wave row of one half
-        constexpr int TPR = BN / 8, RPP = NT / TPR;
-        unsigned char* ep = smem + B8_EPI_OFF;
-        const float* lbias = reinterpret_cast<const float*>(smem + B8_BIAS_OFF + epar * 2048);
-        const int ec = (tid % TPR) * 8, er = tid / TPR;
-        float bv[8], sv[8];
+    }
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            constexpr int kNF[2] = {4, FP1};
-            const int NF = kNF[pass >> 1];
-            const int PR = NF * 16;                                       // rows of this slab
-            const int rbase = (pass >> 1) * 128 + (pass & 1) * PR;        // its first row in the tile
-            const int SWEEPS = PR / RPP;
-            if (wm == (pass & 1)) {
+    for (int pass = 0; pass < 4; ++pass) {
+        constexpr int kNF[2] = {4, FP1};
+        const int NF = kNF[pass >> 1];
+        const int PR = NF * 16;                                       // rows of this slab
+        const int rbase = (pass >> 1) * 128 + (pass & 1) * PR;        // its first row in the tile
+        const int SWEEPS = PR / RPP;
+        if (wm == (pass & 1)) {
 #pragma unroll
-                for (int wh = 0; wh < 2; ++wh)
+            for (int wh = 0; wh < 2; ++wh)
 #pragma unroll
-                    for (int a = 0; a < 2; ++a)
+                for (int a = 0; a < 2; ++a)
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) {
-                            if (b >= NF) continue;
-                            const int ch = wh * 128 + wn * 32 + a * 16 + fk * 4;
-                            *reinterpret_cast<f32x4*>(ep + (b * 16 + frow) * B8_EPI_STRIDE + ch * 4) = acc[pass >> 1][wh][a][b];
-                        }
-            }
-            if (pass == 0) wait_vmcnt<0>();   // the next tile's first K-step has landed; no store is outstanding yet
-            lgkm0();
-            bar();
-            if (pass == 0 && EPI == EPI_BIAS_LEAKY) {
+                    for (int b = 0; b < 4; ++b) {
+                        if (b >= NF) continue;
+                        const int ch = wh * 128 + wn * 32 + a * 16 + fk * 4;
+                        *reinterpret_cast<f32x4*>(smem + (b * 16 + frow) * B8_EPI_STRIDE + ch * 4) = acc[pass >> 1][wh][a][b];
+                    }
+        }
+        __syncthreads();
+        if (EPI == EPI_POOL) {
+            // one item per thread: (window, 8 channels); see igemm_kernel for the pooling rule
+            const int w = tid / TPR, c8 = tid - w * TPR;
+            const int q = ((m0 + rbase) >> 2) + w;
+            if (w < PR / 4 && q * 4 < Mc) {
+                float bvp[8], svp[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    bv[j] = lbias[ec + j];
-                    sv[j] = g.scale ? lbias[256 + ec + j] : 1.0f;
+                    bvp[j] = g.bias[n0 + c8 * 8 + j];
+                    svp[j] = g.scale ? g.scale[n0 + c8 * 8 + j] : 1.0f;
                 }
-            }
-            if (EPI == EPI_POOL) {
-                // one item per thread: (window, 8 channels); see igemm_kernel for the pooling rule
-                const int w = tid / TPR, c8 = tid - w * TPR;
-                const int q = ((em0 + rbase) >> 2) + w;
-                if (w < PR / 4 && q * 4 < Mc) {
-                    float bvp[8], svp[8];
+                bf16x8 best;
+                unsigned packed = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned char* rp = smem + (4 * w + k) * B8_EPI_STRIDE + c8 * 32;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(rp);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(rp + 16);
+                    const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        bvp[j] = lbias[c8 * 8 + j];
-                        svp[j] = g.scale ? lbias[256 + c8 * 8 + j] : 1.0f;
-                    }
-                    bf16x8 best;
-                    unsigned packed = 0;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const unsigned char* rp = ep + (4 * w + k) * B8_EPI_STRIDE + c8 * 32;
-                        const f32x4 v0 = *reinterpret_cast<const f32x4*>(rp);
-                        const f32x4 v1 = *reinterpret_cast<const f32x4*>(rp + 16);
-                        const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const float tv = __builtin_fmaf(v[j], svp[j], bvp[j]);
-                            const bf16_t yv = (bf16_t)(tv > 0.0f ? tv : tv * g.slope);
-                            if (k == 0 || (float)yv > (float)best[j]) {
-                                best[j] = yv;
-                                packed = (packed & ~(3u << (2 * j))) | ((unsigned)k << (2 * j));
-                            }
+                        const float tv = __builtin_fmaf(v[j], svp[j], bvp[j]);
+                        const bf16_t yv = (bf16_t)(tv > 0.0f ? tv : tv * g.slope);
+                        if (k == 0 || (float)yv > (float)best[j]) {
+                            best[j] = yv;
+                            packed = (packed & ~(3u << (2 * j))) | ((unsigned)k << (2 * j));
                         }
                     }
-                    *reinterpret_cast<bf16x8*>(g.out + (long long)q * g.NOUT + en0 + c8 * 8) = best;
-                    g.pool_idx[(long long)q * (g.NOUT / 8) + (en0 >> 3) + c8] = (unsigned short)packed;
                 }
-            } else {
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    if (p >= SWEEPS) continue;
-                    const int row = er + p * RPP;
-                    const int m = em0 + rbase + row;
-                    if (m >= Mc) continue;
-                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(ep + row * B8_EPI_STRIDE + ec * 4);
-                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(ep + row * B8_EPI_STRIDE + ec * 4 + 16);
-                    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                    const long long o = (long long)m * g.NOUT + en0 + ec;
-                    if (EPI == EPI_BIAS_LEAKY) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const float tv = __builtin_fmaf(v[j], sv[j], bv[j]);
-                            v[j] = tv > 0.0f ? tv : tv * g.slope;
-                        }
-                    } else if (EPI == EPI_MASK) {
-                        const bf16x8 av = *reinterpret_cast<const bf16x8*>(g.act + o);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] = (float)av[j] > 0.0f ? v[j] : v[j] * g.slope;
-                    }
-                    bf16x8 ov;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) ov[j] = (bf16_t)v[j];
-                    *reinterpret_cast<bf16x8*>(g.out + o) = ov;
-                }
+                *reinterpret_cast<bf16x8*>(g.out + (long long)q * g.NOUT + n0 + c8 * 8) = best;
+                g.pool_idx[(long long)q * (g.NOUT / 8) + (n0 >> 3) + c8] = (unsigned short)packed;
             }
-            lgkm0();   // this wave's slab reads are done before any wave overwrites the slab
-            bar();
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if (p >= SWEEPS) continue;
+                const int row = er + p * RPP;
+                const int m = m0 + rbase + row;
+                if (m >= Mc) continue;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(smem + row * B8_EPI_STRIDE + ec * 4);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(smem + row * B8_EPI_STRIDE + ec * 4 + 16);
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                const long long o = (long long)m * g.NOUT + n0 + ec;
+                if (EPI == EPI_BIAS_LEAKY) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float tv = __builtin_fmaf(v[j], sv[j], bv[j]);
+                        v[j] = tv > 0.0f ? tv : tv * g.slope;
+                    }
+                } else if (EPI == EPI_MASK) {
+                    const bf16x8 av = *reinterpret_cast<const bf16x8*>(g.act + o);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = (float)av[j] > 0.0f ? v[j] : v[j] * g.slope;
+                }
+                bf16x8 ov;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ov[j] = (bf16_t)v[j];
+                *reinterpret_cast<bf16x8*>(g.out + o) = ov;
+            }
         }
-        if (next >= T) break;
-        stage_k1();    // buffer 1 is free again (the barrier above); K-step 0 landed and is visible (pass 0's wait + barrier)
-        tile = next;
-        par ^= 1;
+        if (pass < 3) __syncthreads();
     }
-}
-
-int cu_count() {
-    static int n = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-            v = 256;
-        return v;
-    }();
-    return n;
 }
 
 template <int EPI, int FP1>
@@ -804,10 +744,9 @@ int launch_igemm8(IgemmArgs& g, hipStream_t s, const char* name) {
     g.mtiles = (int)yfs_cdiv(g.M, 128 + FP1 * 32);
     g.ntiles = g.NOUT / 256;
     auto kern = igemm8_kernel<EPI, FP1>;
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, B8_LDS_P);
-    YFS_REQUIRE(e == hipSuccess, YFS_ERR_LAUNCH, "%s: cannot reserve %d bytes of LDS", name, B8_LDS_P);
-    const int tiles = g.mtiles * g.ntiles, cus = cu_count();
-    kern<<<dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(512), B8_LDS_P, s>>>(g);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, B8_LDS);
+    YFS_REQUIRE(e == hipSuccess, YFS_ERR_LAUNCH, "%s: cannot reserve %d bytes of LDS", name, B8_LDS);
+    kern<<<dim3((unsigned)(g.mtiles * g.ntiles)), dim3(512), B8_LDS, s>>>(g);
     YFS_CHECK_LAUNCH(name);
     return YFS_OK;
 }
