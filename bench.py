@@ -37,7 +37,9 @@ NMS_BYTES_PER_IMG = 108160    # raw head 84,500 + boxes/score/
 # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled
 # per the gfx950 note of MI355X_MICROARCH.md; profiles/r02/pmc_traffic_hbm_kernels.txt), at the sub-benchmarks' own sizes.
 # bench.py cannot run rocprofv3 on itself, so these are the committed measurements, not live values.
-PMC_TRAFFIC_BYTES = {"nms": 109.0e6, "loss": 1.13e9, "assign": 264.0e6}
+# nms: decode launch 104.8 MB + NMS launch 32.1 MB (it re-reads score / class / passing boxes; 4-B reads are over-counted
+# by the doubling, the true figure lies between 126 and 137 MB).
+PMC_TRAFFIC_BYTES = {"nms": 137.0e6, "loss": 1129.5e6, "assign": 264.2e6}
 
 
 def conv_flops_table(model, batch, hw=448):
@@ -185,11 +187,9 @@ def nms_bench(device, iters=20):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    gbs = N * NMS_BYTES_PER_IMG / (ms * 1e-3) / 1e9
     out = {"metric": "NMS images/sec (decode + IoU + class-wise NMS, 13x13x5 anchors, C=20, batch 1024)",
            "value": round(N / (ms * 1e-3), 1), "unit": "images/s", "ms_per_batch": round(ms, 4), "dtype": "f32",
-           "roofline": {"bound": "hbm", "achieved": round(gbs, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": round(gbs / PEAK_HBM_GBS, 5), "traffic": None}}
+           "roofline": _hbm_record(N * NMS_BYTES_PER_IMG, ms, PMC_TRAFFIC_BYTES["nms"])}
     return out
 
 
