@@ -43,14 +43,15 @@ int yfs_last_error(char *buf, size_t n);
 /* Tuning knobs: measurement aids for tools/conv_bench.py, tools/probes and the forced-tile tests.  Process-wide
  * integers, 0 = the library's own choice (the default and the only supported production setting).  Their initial
  * values come from the environment variables of the same name (YFS_IGEMM_TILE, YFS_WGRAD_TILE, YFS_WGRAD_SPLITS,
- * YFS_NMS_FUSED), read once at the first use of any knob.  Changing a knob while another thread launches kernels
+ * YFS_NMS_FUSED, YFS_STEM_KERNEL), read once at the first use of any knob.  Changing a knob while another thread launches kernels
  * affects that thread's tile choice, never its results beyond fp32 summation order.
  *   YFS_KNOB_IGEMM_TILE    forward/dgrad workgroup tile: 128 | 64128 | 224 | 2562 | 256 | 8 (256x256, 8-phase) | 87 (224x256, 8-phase)
  *   YFS_KNOB_WGRAD_TILE    weight-gradient tile: 64 | 12864 | 8 (256x256, 8-phase schedule)
  *   YFS_KNOB_WGRAD_SPLITS  split-K factor of the weight gradient (> 0 forces it)
- *   YFS_KNOB_NMS_FUSED     1: yfs_decode_nms_f32 decodes inside the NMS kernel (one launch) */
+ *   YFS_KNOB_NMS_FUSED     1: yfs_decode_nms_f32 decodes inside the NMS kernel (one launch)
+ *   YFS_KNOB_STEM_KERNEL   1: stem forward + pool on the tiled kernel instead of the weight-stationary one (bit-identical) */
 typedef enum { YFS_KNOB_IGEMM_TILE = 0, YFS_KNOB_WGRAD_TILE = 1, YFS_KNOB_WGRAD_SPLITS = 2, YFS_KNOB_NMS_FUSED = 3,
-               YFS_KNOB_COUNT = 4 } yfs_knob_id;
+               YFS_KNOB_STEM_KERNEL = 4, YFS_KNOB_COUNT = 5 } yfs_knob_id;
 int yfs_set_knob(int knob, int value);
 int yfs_get_knob(int knob);
 

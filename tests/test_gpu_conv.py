@@ -197,18 +197,30 @@ def test_conv_fwd_pool_fused_is_bit_identical(n, cin, cout, k, hw):
 
 
 @pytest.mark.gpu
-def test_stem_fwd_pool_fused_is_bit_identical():
+@pytest.mark.parametrize("n,hw,cout", [(2, 64, 192), (3, 128, 192), (2, 448, 192), (1, 320, 192), (2, 36, 128), (1, 72, 192)])
+def test_stem_fwd_pool_fused_is_bit_identical(n, hw, cout):
+    """Stem + pool in one launch == stem forward followed by the pool kernel, bit for bit (pooled values and window
+    positions).  Cout = 192 with OH % 4 == 0 and OW % 32 == 0 (64, 128, 320, 448) runs the weight-stationary
+    stem_pool_kernel, the other shapes the tiled kernel; where the weight-stationary kernel runs it is also compared
+    with the tiled kernel forced through the knob."""
+    from yolo_from_scratch_amd import _lib
     from yolo_from_scratch_amd import model as ym
-    torch.manual_seed(3)
-    x = torch.rand(2, 3, 64, 64)
-    w = _bf(torch.randn(192, 3, 7, 7) * 0.05)
-    b = torch.randn(192)
+    torch.manual_seed(3 + hw)
+    x = torch.rand(n, 3, hw, hw) - 0.4
+    w = _bf(torch.randn(cout, 3, 7, 7) * 0.05)
+    b = torch.randn(cout) * 0.2
     xs = co.stem_space_to_depth(x.to(DEV))
     w2 = co.stem_weight(co.nhwc(w.to(DEV)))
-    oh, ow, _, _ = co.stem_geometry(64, 64)
+    oh, ow, _, _ = co.stem_geometry(hw, hw)
     y_ref, idx_ref = ym._pool_fwd_idx(co.stem_fwd(xs, w2, b.to(DEV), oh, ow))
     y, idx = co.stem_fwd_pool(xs, w2, b.to(DEV), oh, ow)
     assert torch.equal(y, y_ref) and torch.equal(idx, idx_ref)
+    _lib.set_knob("stem_kernel", 1)
+    try:
+        y_t, idx_t = co.stem_fwd_pool(xs, w2, b.to(DEV), oh, ow)
+    finally:
+        _lib.set_knob("stem_kernel", 0)
+    assert torch.equal(y, y_t) and torch.equal(idx, idx_t)
 
 
 @pytest.mark.gpu

@@ -29,6 +29,8 @@ typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 // Raw buffer descriptor over a whole tensor: loads whose byte offset is >= num_records return zeros in
@@ -1949,6 +1951,234 @@ __global__ void __launch_bounds__(kThreads) stem_s2d_kernel(const TIn* __restric
         o[1] = hi;
     }
 }
+
+// ---- stem forward + 2x2 max pool, weight-stationary -------------------------------------------------------------
+// The stem GEMM has K = 256: four K-steps per tile, so a tiled kernel spends its time filling its pipeline and in the
+// epilogue (igemm_kernel<128,192,..,EPI_POOL>: 0.30 PFLOP/s).  This kernel turns the loop nest around:
+//   * the weights never move: wave (cg, rp) keeps the weight fragments of its CB*16 output channels for the whole K (CB x 8
+//     B fragments = 96 registers at Cout = 192) for the life of the kernel;
+//   * the input is staged as RAW rows of the space-to-depth image, not as per-pixel windows: a strip of 4 output rows
+//     needs 7 input rows = one contiguous piece of xs (7 * Ws * 32 B, 50 KiB at 448^2) which the 8 waves copy with
+//     plain linear LDS-DMA, double-buffered, one barrier per strip.  The 4 x 16 channels of a kernel row are 128
+//     contiguous bytes starting at the pixel, and adjacent pixels are 32 B apart, so the B fragment of 16 adjacent
+//     output pixels is a ds_read_b128 at lane stride 32 B straight from the raw row (conflict-free: the 16-lane groups
+//     of ds_read_b128 cover 16 distinct 16-B slots of the 256-B bank row) - the overlapping windows are never copied;
+//   * a wave's tile is 2 output rows x 32 columns x its channels, with the PIXELS as the A operand: a lane then holds one
+//     channel for 4 adjacent columns, the two rows of a pool window are two accumulators of that lane, so the whole
+//     window is lane-local: bias + LeakyReLU + rounding + first-maximum run in registers with no cross-lane traffic,
+//     and only the pooled tensor and the 2-bit positions are stored.
+// Two waves share a SIMD and free-run inside a strip, so one wave's epilogue VALU overlaps the other's MFMAs.
+// Same K order as the tiled kernel (kernel row by kernel row, 32 elements per MFMA): bit-identical results.
+struct StemPoolArgs {
+    const bf16_t* xs;           // [N,Hs,Ws,16]
+    const bf16_t* w2;           // [Cout][4][64]
+    const float* bias;          // [Cout]
+    bf16_t* out;                // [N,OH/2,OW/2,Cout]
+    unsigned short* pool_idx;   // [N*OH/2*OW/2][Cout/8]
+    int N, Hs, Ws, OH, OW, Cout;
+    unsigned xbytes, obytes, ibytes;
+    float slope;
+    int nstrips;                // N * OH/4
+    int pieces;                 // 1-KiB LDS-DMA pieces per strip
+    int buf_bytes;              // pieces * 1024
+};
+
+#ifdef YFS_STEM_TIMING
+__device__ long long yfs_stem_dbg[64];
+#define STEM_T(v) const long long v = clock64()
+#else
+#define STEM_T(v) do { } while (0)
+#endif
+__device__ __forceinline__ float hw_maxf(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+// LMAX: 0 <= slope <= 1, so LeakyReLU(t) = max(t, t * slope) (one instruction less per value than compare + select;
+// the hardware max returns the non-NaN operand and NaN for two NaNs, like the select form does for t = NaN)
+template <int CB, bool LMAX>
+__global__ void __launch_bounds__(512, 1) stem_pool_kernel(StemPoolArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = wave & 3, rp = wave >> 2;           // channel group, row pair of the strip
+    const int frow = lane & 15, fk = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.xs, g.xbytes);
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr)smem;
+
+    bf16x8 wf[CB][8];
+    float bvl[CB];
+#pragma unroll
+    for (int blk = 0; blk < CB; ++blk) {
+        const int ch = (cg * CB + blk) * 16;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+            wf[blk][kk] = *reinterpret_cast<const bf16x8*>(g.w2 + (size_t)(ch + frow) * 256 + kk * 32 + fk * 8);
+        bvl[blk] = g.bias[ch + frow];
+    }
+
+    const int rowbytes = g.Ws * 32;
+    const int spi = g.OH >> 2, PH = g.OH >> 1, PW = g.OW >> 1, ncb = g.OW >> 5, c8 = g.Cout >> 3;
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(g.out, g.obytes), ri = make_rsrc(g.pool_idx, g.ibytes);
+    // lane (frow, fk) owns channel frow of a block for the pooled pixels fk*2, fk*2+1 of the 8 in a 16-column block
+    const unsigned ovoff = (unsigned)((fk * 2) * g.Cout + frow) * 2u;          // + w * Cout * 2 via the scalar offset
+    const unsigned ivoff = (frow & 7) == 0 ? (unsigned)((fk * 2) * c8 + (frow >> 3)) * 2u : 0xFFFFFF00u;
+    auto issue = [&](int s, int buf) {
+        const int n = s / spi, oh0 = (s - n * spi) * 4;
+        const unsigned src = (unsigned)((n * g.Hs + oh0) * g.Ws) * 32u + (unsigned)lane * 16u;
+        for (int p = wave; p < g.pieces; p += 8)
+            dma16_asm(rx, lds0 + (unsigned)(buf * g.buf_bytes + p * 1024), src + (unsigned)p * 1024u, 0u);
+    };
+
+    int s = blockIdx.x, buf = 0;
+    if (s < g.nstrips) issue(s, 0);
+    for (; s < g.nstrips; s += gridDim.x) {
+#ifdef YFS_STEM_TIMING
+        const long long tb0 = clock64();
+#endif
+        wait_vmcnt<0>();                    // this wave's pieces of strip s have landed (and its stores have left)
+        __builtin_amdgcn_s_barrier();
+#ifdef YFS_STEM_TIMING
+        if (blockIdx.x == 7 && lane == 0) yfs_stem_dbg[wave * 4 + 3] += clock64() - tb0;
+#endif       // ... everyone's have, and everyone is done reading the other buffer
+        if (s + (int)gridDim.x < g.nstrips) issue(s + gridDim.x, buf ^ 1);
+        const int n = s / spi, oh0 = (s - n * spi) * 4;
+        const long long qrow = ((long long)n * PH + (oh0 >> 1) + rp) * PW;
+        const unsigned char* sb = smem + buf * g.buf_bytes + (2 * rp) * rowbytes + frow * 32 + fk * 16;
+#pragma unroll 1
+        for (int cb = 0; cb < ncb; ++cb) {
+            f32x4 acc[2][2][CB];
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int blk = 0; blk < CB; ++blk) acc[dy][hf][blk] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const unsigned char* tb = sb + cb * 1024;
+            // the two waves of a SIMD share its issue slots by priority, then age: alternate the priority tile by tile so
+            // that neither half of the workgroup is the permanent loser (it would keep the other half waiting at the
+            // strip barrier: 10 K of 40 K cycles per strip, tools/probes/stem_phases.py)
+            if ((cb ^ rp) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+            STEM_T(t0);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const int kh = kk >> 1, h = kk & 1;
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const bf16x8 pf = *reinterpret_cast<const bf16x8*>(tb + (dy + kh) * rowbytes + hf * 512 + h * 64);
+#pragma unroll
+                        for (int blk = 0; blk < CB; ++blk)
+                            acc[dy][hf][blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, wf[blk][kk], acc[dy][hf][blk], 0, 0, 0);
+                    }
+            }
+            STEM_T(t1);
+            // epilogue.  MFMA roles: A = pixels, B = weights, so lane (frow, fk) holds channel frow of the block for the
+            // pixel columns fk*4 .. fk*4+3 of the 16-column block: both columns of a pool window are registers of one
+            // lane (r = 0,1 and r = 2,3) and both rows are the two accumulators - the whole window is lane-local.
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                // stores: per-lane offsets are constants of the lane, the tile's position is a scalar offset - no
+                // per-store address arithmetic and no branches (lanes that store nothing carry an out-of-range offset)
+                const unsigned q0 = (unsigned)(qrow + cb * 16 + hf * 8);       // first pooled pixel of the 16-column block
+#pragma unroll
+                for (int blk = 0; blk < CB; ++blk) {
+                    const int ch = (cg * CB + blk) * 16;
+                    // stage by stage over the 8 values of the block (not value by value): with two waves per SIMD nothing
+                    // else hides the latency of a dependent VALU chain
+                    float a[2][4], t[2][4], u[2][4];
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) t[dy][r] = acc[dy][hf][blk][r] + bvl[blk];
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) u[dy][r] = t[dy][r] * g.slope;
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) t[dy][r] = LMAX ? hw_maxf(t[dy][r], u[dy][r]) : (t[dy][r] > 0.0f ? t[dy][r] : u[dy][r]);
+                    unsigned pk[2][2];
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                        for (int r = 0; r < 4; r += 2) {       // one v_cvt_pk_bf16_f32 per pair
+                            const f32x2 pr = {t[dy][r], t[dy][r + 1]};
+                            pk[dy][r >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, bf16x2));
+                        }
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                        for (int r = 0; r < 4; r += 2) {
+                            a[dy][r] = __builtin_bit_cast(float, pk[dy][r >> 1] << 16);
+                            a[dy][r + 1] = __builtin_bit_cast(float, pk[dy][r >> 1] & 0xFFFF0000u);
+                        }
+                    unsigned bits = 0;
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) {
+                        // first maximum in window order (dy, dx) = (0,0) (0,1) (1,0) (1,1), as a two-level tree: the
+                        // first maximum of each row, then the second row only if strictly greater
+                        const bool m0 = a[0][2 * w + 1] > a[0][2 * w], m1 = a[1][2 * w + 1] > a[1][2 * w];
+                        const float v0 = m0 ? a[0][2 * w + 1] : a[0][2 * w], v1 = m1 ? a[1][2 * w + 1] : a[1][2 * w];
+                        const bool m2 = v1 > v0;
+                        const float b = m2 ? v1 : v0;
+                        const unsigned id = m2 ? (m1 ? 3u : 2u) : (m0 ? 1u : 0u);
+                        __builtin_amdgcn_raw_buffer_store_b16((short)(__builtin_bit_cast(unsigned, b) >> 16), ro, ovoff,
+                                                              ((q0 + w) * (unsigned)g.Cout + (unsigned)ch) * 2u, 0);
+                        bits |= id << (16 * w);
+                    }
+                    // 2-bit positions of 8 adjacent channels -> one u16 per pooled pixel: OR over the 8 lanes
+                    bits <<= 2 * (frow & 7);
+                    bits |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)bits, 0xB1, 0xF, 0xF, false);    // lane ^ 1
+                    bits |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)bits, 0x4E, 0xF, 0xF, false);    // lane ^ 2
+                    bits |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)bits, 0x141, 0xF, 0xF, false);   // mirror inside 8 lanes
+                    const unsigned isoff = (q0 * (unsigned)c8 + (unsigned)(ch >> 3)) * 2u;
+                    __builtin_amdgcn_raw_buffer_store_b16((short)bits, ri, ivoff, isoff, 0);
+                    __builtin_amdgcn_raw_buffer_store_b16((short)(bits >> 16), ri, ivoff, isoff + (unsigned)c8 * 2u, 0);
+                }
+            }
+#ifdef YFS_STEM_TIMING
+            {
+                STEM_T(t2);
+                if (blockIdx.x == 7 && lane == 0) {
+                    yfs_stem_dbg[wave * 4 + 0] += t1 - t0;
+                    yfs_stem_dbg[wave * 4 + 1] += t2 - t1;
+                    yfs_stem_dbg[wave * 4 + 2] += 1;
+                }
+            }
+#endif
+        }
+        buf ^= 1;
+    }
+}
+
+#ifdef YFS_STEM_TIMING
+}  // namespace
+extern "C" __attribute__((visibility("default"))) int yfs_debug_stem_times(long long* out, int reset) {
+    if (reset) { long long z[64] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(yfs_stem_dbg), z, sizeof(z)); }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(yfs_stem_dbg), 64 * sizeof(long long));
+}
+namespace {
+#endif
+int launch_stem_pool(const StemPoolArgs& a, hipStream_t stream) {
+    StemPoolArgs g = a;
+    const int strip_bytes = 7 * g.Ws * 32;
+    g.pieces = (strip_bytes + 1023) / 1024;
+    g.buf_bytes = g.pieces * 1024;
+    g.nstrips = g.N * (g.OH / 4);
+    const size_t lds = 2 * (size_t)g.buf_bytes;
+    auto kern = (g.slope >= 0.0f && g.slope <= 1.0f) ? stem_pool_kernel<3, true> : stem_pool_kernel<3, false>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    YFS_REQUIRE(e == hipSuccess, YFS_ERR_LAUNCH, "yfs_conv2d_stem_fwd_pool_bf16: cannot reserve %zu bytes of LDS", lds);
+    // persistent: one workgroup per CU walks the strips (3584 strips at batch 64 = 14 per CU)
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        cus = 256;
+    const int grid = g.nstrips < cus ? g.nstrips : cus;
+    kern<<<dim3((unsigned)grid), dim3(512), lds, stream>>>(g);
+    YFS_CHECK_LAUNCH("stem_pool_kernel");
+    return YFS_OK;
+}
 }  // namespace
 
 YFS_API int yfs_stem_space_to_depth_bf16(const void* x, int x_is_f32, int64_t stride_n, int64_t stride_c, int64_t stride_h,
@@ -1991,6 +2221,18 @@ YFS_API int yfs_conv2d_stem_fwd_pool_bf16(const void* xs, const void* w2, const 
     if (rc) return rc;
     YFS_REQUIRE(OH % 2 == 0 && OW % 2 == 0, YFS_ERR_UNSUPPORTED,
                 "yfs_conv2d_stem_fwd_pool_bf16: conv output %dx%d must be even for the fused 2x2 pool", OH, OW);
+    // weight-stationary kernel where its shape assumptions hold (the reference's 448^2 stem does), else the tiled kernel
+    if (yfs_knob(YFS_KNOB_STEM_KERNEL) != 1 && Cout == 192 && OH % 4 == 0 && OW % 32 == 0 &&
+        2 * (size_t)((7 * Ws * 32 + 1023) / 1024) * 1024 <= 160 * 1024) {
+        StemPoolArgs a = {};
+        a.xs = (const bf16_t*)xs; a.w2 = (const bf16_t*)w2; a.bias = bias; a.out = (bf16_t*)y_pooled;
+        a.pool_idx = (unsigned short*)pool_idx;
+        a.N = (int)N; a.Hs = Hs; a.Ws = Ws; a.OH = OH; a.OW = OW; a.Cout = Cout; a.slope = slope;
+        a.xbytes = (unsigned)(N * Hs * Ws * kStemC * 2);
+        a.obytes = (unsigned)(N * (OH / 2) * (OW / 2) * Cout * 2);
+        a.ibytes = (unsigned)(N * (OH / 2) * (OW / 2) * (Cout / 8) * 2);
+        return launch_stem_pool(a, (hipStream_t)stream);
+    }
     IgemmArgs g = {};
     g.x = (const bf16_t*)xs; g.w = (const bf16_t*)w2; g.bias = bias; g.out = (bf16_t*)y_pooled; g.pool_idx = (unsigned short*)pool_idx;
     g.N = (int)N; g.H = Hs; g.W = Ws; g.C = 64; g.PS = stem_ps(); g.OH = OH; g.OW = OW; g.NOUT = Cout;

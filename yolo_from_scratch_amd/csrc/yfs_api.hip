@@ -31,7 +31,7 @@ YFS_API int yfs_last_error(char* buf, size_t n) {
 namespace {
 std::atomic<int> g_knob[YFS_KNOB_COUNT];
 std::atomic<int> g_knob_init{0};
-const char* const kKnobEnv[YFS_KNOB_COUNT] = {"YFS_IGEMM_TILE", "YFS_WGRAD_TILE", "YFS_WGRAD_SPLITS", "YFS_NMS_FUSED"};
+const char* const kKnobEnv[YFS_KNOB_COUNT] = {"YFS_IGEMM_TILE", "YFS_WGRAD_TILE", "YFS_WGRAD_SPLITS", "YFS_NMS_FUSED", "YFS_STEM_KERNEL"};
 void knob_init() {   // the environment gives the initial values, read once (racing first calls write the same values)
     if (g_knob_init.load(std::memory_order_acquire)) return;
     for (int k = 0; k < YFS_KNOB_COUNT; ++k) {
