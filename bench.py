@@ -409,7 +409,7 @@ def main():
                                           (" buckets; fc.1 as all-gathered gradient factors" if opt._defer else ""))
                        if world > 1 else None},
             "final_loss": round(final_loss, 5),
-            "roofline": {"bound": "mfma", "kernel": "conv implicit-GEMM set (igemm_kernel / igemm8_kernel fwd+dgrad, wgrad_kernel / wgrad8_kernel)",
+            "roofline": {"bound": "mfma", "kernel": "conv implicit-GEMM set (igemm_kernel / igemm8_kernel / stem_pool_kernel fwd+dgrad, wgrad_kernel / wgrad8_kernel)",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
                          "algorithmic_tflop_per_step": round(conv_flops / 1e12, 4), "conv_ms_per_step": round(conv_ms, 3),
