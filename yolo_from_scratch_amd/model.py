@@ -264,7 +264,8 @@ class _BackboneFn(torch.autograd.Function):
         h = x
         # operand copies of every non-stem layer in one launch
         convs = [i for i, st in enumerate(stages) if st != "P"]
-        todo = [(params[2 * j], convs[j] > 0) for j in range(len(convs)) if params[2 * j].shape[1] % 64 == 0]
+        want_bwd = any(ctx.needs_input_grad)      # all False under torch.no_grad(): no transposed copies for dgrad then
+        todo = [(params[2 * j], convs[j] > 0 and want_bwd) for j in range(len(convs)) if params[2 * j].shape[1] % 64 == 0]
         prepared = iter(_ConvPlan.prepare(todo))
         pi = 0
         fused_idx = None
