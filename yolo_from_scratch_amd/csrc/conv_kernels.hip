@@ -432,22 +432,23 @@ int launch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
 // The 2-stage loops above pay one vmcnt(0) + barrier hand-off per K-step with every wave in the same state: all
 // loading, then all multiplying.  Here the tile is cut into four 16 KiB half-tiles per K-step (pixel rows 0-127 /
 // 128-255 = P0 / P1, weight rows W0 / W1; two LDS buffers of four half-tiles = 128 KiB), a K-step into four phases,
-// one 64 x 32 output quadrant of every wave each (wave = 2 x 2 quadrants: 128 pixels x 64 channels, 128 accumulator
-// registers), and the two wave rows run one barrier apart: while waves 0-3 multiply (16 MFMAs between two barriers),
+// two 64 x 32 output quadrants of every wave each (wave = 2 x 2 quadrants: 128 pixels x 64 channels, 128 accumulator
+// registers), and the two wave rows run one barrier apart: while waves 0-3 multiply (32 MFMAs between two barriers),
 // waves 4-7 — their partners on the same four SIMDs — read fragments and issue the next LDS-DMA, and vice versa, so
 // the matrix pipe of every SIMD always has one wave feeding it.
-//   phase 1: read W0, P0 fragments | stage P1 of tile t+1 | MFMA quadrant (P0, W0)
-//   phase 2: read W1               | stage W0 of tile t+2 | MFMA (P0, W1)
-//   phase 3: read P1               | stage P0 of tile t+2 | MFMA (P1, W1)
-//   phase 4: (W0 stays in regs)    | stage W1 of tile t+2 | MFMA (P1, W0)   + the only vmcnt wait of the K-step
-// A half-tile is restaged as soon as its fragments are in registers (>= 2 phases after it was read; W0 one phase
-// after, which is why every wave retires its reads with lgkmcnt(0) BEFORE the phase's first barrier), i.e. the loads
-// run two K-steps ahead with two buffers.  vmcnt(6) in phase 4 leaves the three half-tiles issued in phases 2-4 in
-// flight (2 LDS-DMA instructions per wave and half-tile) and retires everything older = all of tile t+1, which is
-// first read two barriers later.  Barriers are raw s_barrier (a __syncthreads() would drain the DMA queue).
+//   phase A: read W0, P0, W1 fragments | stage P1 of tile t+1           | MFMA quadrants (P0, W0), (P0, W1)
+//   phase B: read P1                   | stage W0, P0, W1 of tile t+2   | MFMA (P1, W1), (P1, W0)   + the only vmcnt wait
+// (Round 2 started with four phases of 16 MFMAs, one half-tile staged per phase; merging them pairwise halves the
+// barriers per K-step and measured 1.6-3 % faster on the same box for every layer that runs this kernel.)
+// A half-tile is restaged one phase after its fragments were read, which is why every wave retires its reads with
+// lgkmcnt(0) BEFORE the phase's first barrier, i.e. the loads run two K-steps ahead with two buffers.  vmcnt(6) in
+// phase B leaves the three half-tiles just issued in flight (2 LDS-DMA instructions per wave and half-tile) and
+// retires everything older = all of tile t+1, which is first read two barriers later.  Barriers are raw s_barrier (a
+// __syncthreads() would drain the DMA queue).
 constexpr int B8_HALF = 128 * 128;     // one half-tile: 128 rows x 128 B
 constexpr int B8_BUF = 4 * B8_HALF;    // [P0 | P1 | W0 | W1]
 constexpr int B8_LDS = 2 * B8_BUF;
+constexpr int B8_LDS_IG = B8_LDS + 512 * 32;   // igemm8_kernel: + 8 words of staging state per thread
 constexpr int B8_EPI_STRIDE = 256 * 4 + 16;   // epilogue: four slabs of <= 64 rows of the fp32 tile through the ring
 
 // FP1 = pixel fragments per wave in the SECOND pixel half-tile: 4 -> 256-row tile, 3 -> 224-row tile (P1 holds 96 rows,
@@ -469,8 +470,10 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
     // ---- staging coordinates: 4 pixel rows and 4 weight rows per thread (2 per half-tile) -----------------------------
     const int chunk = (lane & 7) ^ (lane >> 3);   // source-side XOR swizzle (see igemm_kernel)
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.x, g.xbytes), rw = make_rsrc(g.w, g.wbytes);
-    int bh[4], bw[4];
-    unsigned rowbyte[4];
+    // per-row staging state lives in LDS behind the ring (8 words per thread; read back once per tap): in registers it is
+    // what pushed the two-phase K-step over 256 VGPRs.  st[j] = byte offset of row j's tap-(0,0) source pixel,
+    // st[4 + j] = (bh << 16) | (bw & 0xFFFF), that pixel's row / column (both within +-16 K: dispatch_igemm checks)
+    unsigned* const st = reinterpret_cast<unsigned*>(smem + B8_LDS) + tid * 8;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {   // j = half * 2 + i: tile row half*128 + wave*16 + i*8 + (lane >> 3)
         const int hr = wave * 16 + (j & 1) * 8 + (lane >> 3);   // row inside the half-tile
@@ -490,13 +493,12 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
                 oh = rem / OWc;
                 ow = rem - oh * OWc;
             }
-            bh[j] = oh * g.s_mul - g.pad;
-            bw[j] = ow * g.s_mul - g.pad;
-            rowbyte[j] = (unsigned)(((long long)(n * g.H + bh[j]) * g.W + bw[j]) * g.PS * 2) + chunk * 16;
+            const int bh = oh * g.s_mul - g.pad, bw = ow * g.s_mul - g.pad;
+            st[4 + j] = ((unsigned)bh << 16) | ((unsigned)bw & 0xFFFFu);
+            st[j] = (unsigned)(((long long)(n * g.H + bh) * g.W + bw) * g.PS * 2) + chunk * 16;
         } else {
-            bh[j] = -(1 << 28);
-            bw[j] = -(1 << 28);
-            rowbyte[j] = 0;
+            st[4 + j] = 0xC000C000u;   // (-16384, -16384): outside for every tap
+            st[j] = 0;
         }
     }
     const unsigned ktot = (unsigned)(g.KH * g.KW * g.C);
@@ -511,11 +513,12 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
     constexpr unsigned kOutside = 0xFFF00000u;
     auto tap_offsets = [&]() {
         const unsigned tapoff = (unsigned)(((kh * g.W + kw) * g.PS) * 2);
+        const u32x4 rb = *reinterpret_cast<const u32x4*>(st), hw = *reinterpret_cast<const u32x4*>(st + 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int sh = bh[j] + kh, sw = bw[j] + kw;
+            const int sh = ((int)hw[j] >> 16) + kh, sw = (int)(short)(hw[j] & 0xFFFFu) + kw;
             const bool ok = (unsigned)sh < (unsigned)g.H && (unsigned)sw < (unsigned)g.W;
-            xoff[j] = ok ? rowbyte[j] + tapoff : kOutside;
+            xoff[j] = ok ? rb[j] + tapoff : kOutside;
         }
     };
     auto advance = [&]() {
@@ -602,37 +605,30 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
     auto tile = [&](int t, auto buf_tag) {
         constexpr int BUF = decltype(buf_tag)::value;
         const unsigned char* tb = smem + BUF * B8_BUF;
-        // phase 1
+        // phase A
         read_W(tb + 2 * B8_HALF, w0f);
         read_P(tb, F4);
+        read_W(tb + 3 * B8_HALF, w1f);
         if (t + 1 < nit) stage_P(1, BUF ^ 1);
         lgkm0();
         bar();
         mfma16(acc[0][0], w0f, F4);
-        bar();
-        // phase 2
-        read_W(tb + 3 * B8_HALF, w1f);
-        advance();
-        if (ts < nit) stage_W(0, BUF);
-        lgkm0();
-        bar();
         mfma16(acc[0][1], w1f, F4);
         bar();
-        // phase 3
+        // phase B
         read_P(tb + B8_HALF, F1);
-        if (ts < nit) stage_P(0, BUF);
-        lgkm0();
-        bar();
-        mfma16(acc[1][1], w1f, F1);
-        bar();
-        // phase 4
+        advance();
         if (ts < nit) {
+            stage_W(0, BUF);
+            stage_P(0, BUF);
             stage_W(1, BUF);
             wait_vmcnt<6>();
         } else {
             wait_vmcnt<0>();
         }
+        lgkm0();
         bar();
+        mfma16(acc[1][1], w1f, F1);
         mfma16(acc[1][0], w0f, F1);
         bar();
     };
@@ -746,9 +742,9 @@ int launch_igemm8(IgemmArgs& g, hipStream_t s, const char* name) {
     g.mtiles = (int)yfs_cdiv(g.M, 128 + FP1 * 32);
     g.ntiles = g.NOUT / 256;
     auto kern = igemm8_kernel<EPI, FP1>;
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, B8_LDS);
-    YFS_REQUIRE(e == hipSuccess, YFS_ERR_LAUNCH, "%s: cannot reserve %d bytes of LDS", name, B8_LDS);
-    kern<<<dim3((unsigned)(g.mtiles * g.ntiles)), dim3(512), B8_LDS, s>>>(g);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, B8_LDS_IG);
+    YFS_REQUIRE(e == hipSuccess, YFS_ERR_LAUNCH, "%s: cannot reserve %d bytes of LDS", name, B8_LDS_IG);
+    kern<<<dim3((unsigned)(g.mtiles * g.ntiles)), dim3(512), B8_LDS_IG, s>>>(g);
     YFS_CHECK_LAUNCH(name);
     return YFS_OK;
 }
@@ -778,9 +774,11 @@ int dispatch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
     const int force = yfs_knob(YFS_KNOB_IGEMM_TILE);
     if (g.NOUT % 192 == 0 && g.NOUT % 128 != 0 && force != 64) return launch_igemm<128, 192, 2, 2, 2, EPI, SUB>(g, s, name);
     if (g.NOUT % 128 != 0) return launch_igemm<128, 64, 2, 2, 2, EPI, SUB>(g, s, name);
+    // (igemm8_kernel packs a row's source coordinates into 16 bits each)
+    const bool ok8 = g.NOUT % 256 == 0 && g.H < 16000 && g.W < 16000 && g.OH * g.s_mul < 16000 && g.OW * g.s_mul < 16000;
     if constexpr (!SUB) {
-        if (force == 8 && g.NOUT % 256 == 0) return launch_igemm8<EPI, 4>(g, s, name);
-        if (force == 87 && g.NOUT % 256 == 0) return launch_igemm8<EPI, 3>(g, s, name);
+        if (force == 8 && ok8) return launch_igemm8<EPI, 4>(g, s, name);
+        if (force == 87 && ok8) return launch_igemm8<EPI, 3>(g, s, name);
     }
     if (force == 256) return launch_igemm<256, 128, 4, 2, 3, EPI, SUB>(g, s, name);
     if (force == 64128) return launch_igemm<64, 128, 2, 2, 2, EPI, SUB>(g, s, name);
@@ -792,7 +790,7 @@ int dispatch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
         // and workgroup turnover, so it needs long K and a grid that fills the CUs: K >= 2304 (1728 for the pool-fused
         // form) and at least 200 tiles.  224 rows when that needs fewer or shorter rounds.
         const int kdepth = g.KH * g.KW * g.C;
-        if (force == 0 && g.NOUT % 256 == 0 && kdepth >= (EPI == EPI_POOL ? 1728 : 2304)) {
+        if (force == 0 && ok8 && kdepth >= (EPI == EPI_POOL ? 1728 : 2304)) {
             const long long t224 = yfs_cdiv(g.M, 224) * (g.NOUT / 256), t256 = yfs_cdiv(g.M, 256) * (g.NOUT / 256);
             const double per = kdepth / 64 * 1.17;
             const double c224 = (double)yfs_cdiv(t224, 256) * (12.0 + per * 0.95), c256 = (double)yfs_cdiv(t256, 256) * (12.0 + per);
