@@ -297,7 +297,11 @@ def test_wgrad_8phase_kernel_matches_default(n, cin, cout, k, s, hw):
     x = co.nhwc((torch.rand(n, cin, hw, hw, generator=g) - 0.4).to(DEV), torch.bfloat16)
     oh, ow = co.out_hw(hw, hw, k, s)
     dz = co.nhwc(torch.randn(n, cout, oh, ow, generator=g).to(DEV), torch.bfloat16)
-    dw_ref, db_ref = co.conv_wgrad(x, dz, k, s)
+    L.set_knob("wgrad_tile", 128)          # wgrad_kernel with its own tile choice (auto may already pick wgrad8_kernel)
+    try:
+        dw_ref, db_ref = co.conv_wgrad(x, dz, k, s)
+    finally:
+        L.set_knob("wgrad_tile", 0)
     for splits in (1, 3):
         L.set_knob("wgrad_tile", 8)
         L.set_knob("wgrad_splits", splits)

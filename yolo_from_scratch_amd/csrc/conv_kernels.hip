@@ -1371,14 +1371,12 @@ __global__ void __launch_bounds__(512, 2) wgrad8_kernel(WgradArgs g) {
     // lane&15 = 16-byte LDS slot, which receives global chunk wg_swz(pixel, slot) (source-side swizzle)
     constexpr unsigned kPixOOB = 0xFFFF0000u;
     unsigned zoff[2], xch[2];
-    int xsrc[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int pixel = (wave * 2 + i) * 4 + (lane >> 4);
         const int cs = wg_swz<16>(pixel, lane & 15);
         zoff[i] = ((unsigned)pixel * (unsigned)g.Cout + (unsigned)(co0 + cs * 8)) * 2u;
         xch[i] = cs < XCH ? (unsigned)cs * 16u : kPixOOB;   // (192-channel tile: slots 12-15 of a row fetch nothing)
-        xsrc[i] = (i * 4 + (lane >> 4)) * 4;                // bpermute address of the lane that holds this pixel's offset
     }
     // lane l keeps the source offset of pixel w*8 + (l&7) of k-tile ktg + (l>>3): eight k-tiles per refresh
     unsigned pixcache = 0;
@@ -1400,7 +1398,8 @@ __global__ void __launch_bounds__(512, 2) wgrad8_kernel(WgradArgs g) {
         const int grp = ((k - kt0) & 7) * 32;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const unsigned pv = (unsigned)__builtin_amdgcn_ds_bpermute(xsrc[i] + grp, (int)pixcache);
+            // (i * 4 + (lane >> 4)) * 4 = bpermute address of the lane that holds this pixel's offset
+            const unsigned pv = (unsigned)__builtin_amdgcn_ds_bpermute((i * 4 + (lane >> 4)) * 4 + grp, (int)pixcache);
             const unsigned sum = pv + xch[i];
             xo[i] = (FX == 4 || xch[i] != kPixOOB) ? sum : kPixOOB;   // (OOB + OOB would wrap)
         }
@@ -1426,9 +1425,6 @@ __global__ void __launch_bounds__(512, 2) wgrad8_kernel(WgradArgs g) {
     f32x4 accdb[2][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) (&accdb[0][0])[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bf16x8 ones;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.0f;
     const bool do_db = g.dbpart != nullptr;
     int dbc = kt0 % inner;
 
@@ -1436,7 +1432,7 @@ __global__ void __launch_bounds__(512, 2) wgrad8_kernel(WgradArgs g) {
     const int g4 = lane >> 4, li = lane & 15;
     const int tr_pix = 8 * g4 + (li >> 2), tr_ch = 4 * (li & 3);
     typedef bf16x4 __attribute__((address_space(3)))* tr_ptr;
-    bf16x8 xf[FX][2], zf[2][2];   // (Z0 is read again in phase 4 rather than kept: 16 registers)
+    bf16x8 xf[FX][2], z0f[2][2], z1f[2][2];
     // one address per (fragment, pixel group 0-3 / 4-7); K-half, half-tile and buffer are immediate offsets
     const unsigned char* xa[FX][2];
     const unsigned char* za[2][2];
@@ -1458,7 +1454,7 @@ __global__ void __launch_bounds__(512, 2) wgrad8_kernel(WgradArgs g) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) xf[b][ks] = read_frag(xa[b][0], xa[b][1], hoff + ks * 8192);
     };
-    auto read_Z = [&](int hoff) {
+    auto read_Z = [&](int hoff, bf16x8 (&zf)[2][2]) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1477,6 +1473,10 @@ __global__ void __launch_bounds__(512, 2) wgrad8_kernel(WgradArgs g) {
     // bias gradient: column sums of dz as MFMAs against ones; the `inner` workgroups that share a dz slab take every
     // inner-th k-tile each and the two wave rows one 32-pixel half each (as wgrad_kernel)
     auto mfma_db = [&](f32x4 (&c)[2], const bf16x8 (&zf)[2][2]) {
+        // the all-ones operand is rebuilt here (one K-step in `inner` uses it): four registers not held across the loop
+        unsigned one2 = 0x3F803F80u;
+        asm volatile("" : "+v"(one2));
+        const bf16x8 ones = __builtin_bit_cast(bf16x8, (u32x4){one2, one2, one2, one2});
 #pragma unroll
         for (int a = 0; a < 2; ++a)
             c[a] = wm == 0 ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf[a][0], ones, c[a], 0, 0, 0)
@@ -1489,16 +1489,18 @@ __global__ void __launch_bounds__(512, 2) wgrad8_kernel(WgradArgs g) {
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    // phases (staging order differs from igemm8_kernel because Z0 is read twice):
-    //   1: read Z0, X0 | stage Z0 of tile t+1 | MFMA (X0, Z0)      3: read X1 | stage Z1 of tile t+2 | MFMA (X1, Z1)
-    //   2: read Z1     | stage X0 of tile t+2 | MFMA (X0, Z1)      4: read Z0 | stage X1 of tile t+2, vmcnt | MFMA (X1, Z0)
-    // every half-tile is restaged one phase after its last read, which the lgkmcnt(0) before the barrier has retired
+    // two phases per K-step (as igemm8_kernel), 32 MFMAs each:
+    //   A: read Z0, X0, Z1 | stage X1 of tile t+1            | MFMA (X0, Z0), (X0, Z1) (+ the bias-gradient MFMAs)
+    //   B: read X1         | stage Z0, X0, Z1 of tile t+2, vmcnt | MFMA (X1, Z1), (X1, Z0)
+    // every half-tile is restaged one phase after its last read, which the lgkmcnt(0) before the barrier has retired.
+    // xo holds the X source offsets of tile t+2 from phase A on: phase B stages X0 of t+2 with them and phase A of the
+    // next tile X1 of (its) t+1 = the same tile.
     pixcache = pixel_offsets(kt0);
     x_offsets(kt0);
     stage_Z(0, 0, kt0); stage_X(0, 0); stage_Z(1, 0, kt0); stage_X(1, 0);
     if (nit > 1) {
         x_offsets(kt0 + 1);
-        stage_X(0, 1); stage_Z(1, 1, kt0 + 1); stage_X(1, 1);   // (Z0 of tile 1: phase 1 of tile 0)
+        stage_Z(0, 1, kt0 + 1); stage_X(0, 1); stage_Z(1, 1, kt0 + 1);   // (X1 of tile 1: phase A of tile 0)
         wait_vmcnt<6>();
     } else {
         wait_vmcnt<0>();
@@ -1511,45 +1513,38 @@ __global__ void __launch_bounds__(512, 2) wgrad8_kernel(WgradArgs g) {
         const bool dbmode = do_db && dbc == tci;
         dbc = dbc + 1 == inner ? 0 : dbc + 1;
         const int k1 = kt0 + t + 1, k2 = kt0 + t + 2;
-        // phase 1
-        read_Z((BUF * 2) * B8_HALF);
+        // phase A
+        read_Z((BUF * 2) * B8_HALF, z0f);
         read_X((BUF * 2) * B8_HALF);
-        if (k1 < kt1) stage_Z(0, BUF ^ 1, k1);
+        read_Z((BUF * 2 + 1) * B8_HALF, z1f);
+        if (k1 < kt1) stage_X(1, BUF ^ 1);
         if (k2 < kt1) {
             if (((k2 - kt0) & 7) == 0) pixcache = pixel_offsets(k2);
             x_offsets(k2);
         }
         lgkm0();
         bar();
-        mfma_q(acc[0][0], zf);
-        if (dbmode) mfma_db(accdb[0], zf);
+        mfma_q(acc[0][0], z0f);
+        mfma_q(acc[0][1], z1f);
+        if (dbmode) {
+            mfma_db(accdb[0], z0f);
+            mfma_db(accdb[1], z1f);
+        }
         bar();
-        // phase 2
-        read_Z((BUF * 2 + 1) * B8_HALF);
-        if (k2 < kt1) stage_X(0, BUF);
-        lgkm0();
-        bar();
-        mfma_q(acc[0][1], zf);
-        if (dbmode) mfma_db(accdb[1], zf);
-        bar();
-        // phase 3
+        // phase B
         read_X((BUF * 2 + 1) * B8_HALF);
-        if (k2 < kt1) stage_Z(1, BUF, k2);
-        lgkm0();
-        bar();
-        mfma_q(acc[1][1], zf);
-        bar();
-        // phase 4
-        read_Z((BUF * 2) * B8_HALF);
         if (k2 < kt1) {
-            stage_X(1, BUF);
+            stage_Z(0, BUF, k2);
+            stage_X(0, BUF);
+            stage_Z(1, BUF, k2);
             wait_vmcnt<6>();
         } else {
             wait_vmcnt<0>();
         }
         lgkm0();
         bar();
-        mfma_q(acc[1][0], zf);
+        mfma_q(acc[1][1], z1f);
+        mfma_q(acc[1][0], z0f);
         bar();
     };
     int t = 0;
@@ -1696,7 +1691,7 @@ WgradPlan plan_wgrad(int64_t M, int Cin, int Cout, int taps, bool wide192 = fals
     p.use8 = false;
     const int force_tile8 = yfs_knob(YFS_KNOB_WGRAD_TILE);
     if (plain && !wide192 && Cout % 256 == 0 && (Cin % 256 == 0 || Cin == 192) &&
-        (force_tile8 == 8 || (force_tile8 == 0 && taps > 1 && Cin % 256 == 0))) {
+        (force_tile8 == 8 || (force_tile8 == 0 && taps > 1))) {
         // 8-phase kernel: one workgroup per CU, so the grid runs in rounds of 256; same cost model as below
         p.use8 = true;
         p.bx = Cin % 256 == 0 ? 256 : 192;
@@ -1706,9 +1701,10 @@ WgradPlan plan_wgrad(int64_t M, int Cin, int Cout, int taps, bool wide192 = fals
         p.ktiles = (int)yfs_cdiv(M, 64);
         const int tiles = p.citiles * p.cotiles * taps;
         const int max_splits = p.ktiles / 8 > 0 ? p.ktiles / 8 : 1;
-        // (measured: L7 561 -> 437 us, L10 147 -> 126, L18 587 -> 455, L21 164 -> 132, L24 312 -> 246, L25 / L26 112 -> 95;
-        //  the 1x1 layers and the 192-channel ci tile of L2 are slower than wgrad_kernel and stay there unless forced)
-        const double t_tile = p.bx == 256 ? 1.50 : 1.35;                      // us per 64-pixel k-tile
+        // (measured against wgrad_kernel: L7 561 -> 399 us, L10 147 -> 115, L18 587 -> 399, L21 164 -> 119, L24 312 -> 231,
+        //  L25 / L26 112 -> 86, L2 (192-channel ci tile) 830 -> 751; the 1x1 layers are HBM-bound and stay on wgrad_kernel
+        //  unless forced)
+        const double t_tile = p.bx == 256 ? 1.38 : 1.25;                      // us per 64-pixel k-tile
         const double t_slab = (double)Cout * taps * Cin * 8.0 / 4.0e6;        // us per partial copy (write + read at 4 TB/s)
         double best = 1e30;
         int best_per = p.ktiles;
