@@ -15,7 +15,7 @@ for f in sorted(glob.glob(os.path.join(root, "p*", "*counter_collection.csv"))):
     seen = set()
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
-        m = re.search(r"(igemm8?_kernel<[^>]*>|wgrad8?_kernel<[^>]*>|splitk_reduce_kernel<[^>]*>)", name)
+        m = re.search(r"(igemm8?_kernel<[^>]*>|wgrad8?_kernel<[^>]*>|stem_pool_kernel<[^>]*>|splitk_reduce_kernel<[^>]*>)", name)
         if not m:
             continue
         k = m.group(1).replace(" ", "")
@@ -26,7 +26,7 @@ for f in sorted(glob.glob(os.path.join(root, "p*", "*counter_collection.csv"))):
             dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
         res[k] = (r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Scratch_Size"], r["Workgroup_Size"])
 CUS, SIMDS, XCDS = 256, 4, 8
-print("# per dispatch averages; conv_bench layers 2, 7, 18, 24 (batch 64), ops fwd, dgrad, wgrad; one counter group per rocprofv3 run")
+print("# per dispatch averages; conv_bench layers 0, 2, 7, 18, 24 (batch 64), ops fwdpool, fwd, dgrad, wgrad; one counter group per rocprofv3 run")
 print("# mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 4 SIMDs x 256 CUs); clock = GRBM_GUI_ACTIVE / 8 / duration")
 rows = sorted(acc.items(), key=lambda kv: -sum(dur[kv[0]]))
 for k, c in rows:
