@@ -247,8 +247,7 @@ def _side_stream(device):
     """Second HIP stream per device for the weight-gradient kernels of the backward chain."""
     key = (device.type, device.index)
     if key not in _SIDE:
-        prio = os.environ.get("YFS_SIDE_PRIO")
-        _SIDE[key] = torch.cuda.Stream(device=device, priority=int(prio)) if prio is not None else torch.cuda.Stream(device=device)
+        _SIDE[key] = torch.cuda.Stream(device=device)
         from . import dp
         dp.register_producer_stream(_SIDE[key])
     return _SIDE[key]
