@@ -1987,8 +1987,11 @@ __device__ __forceinline__ float hw_maxf(float a, float b) { float r; asm("v_max
 
 // LMAX: 0 <= slope <= 1, so LeakyReLU(t) = max(t, t * slope) (one instruction less per value than compare + select;
 // the hardware max returns the non-NaN operand and NaN for two NaNs, like the select form does for t = NaN)
+constexpr int kStemOutRow = 96, kStemIdxOff = 16 * kStemOutRow, kStemPatch = 2048;   // per-wave LDS patch (CB = 3)
+
 template <int CB, bool LMAX>
 __global__ void __launch_bounds__(512, 1) stem_pool_kernel(StemPoolArgs g) {
+    static_assert(CB == 3, "the output patch layout assumes 48 channels per wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __attribute__((address_space(3))) void* lds_ptr;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -2013,8 +2016,16 @@ __global__ void __launch_bounds__(512, 1) stem_pool_kernel(StemPoolArgs g) {
     const int spi = g.OH >> 2, PH = g.OH >> 1, PW = g.OW >> 1, ncb = g.OW >> 5, c8 = g.Cout >> 3;
     const __amdgpu_buffer_rsrc_t ro = make_rsrc(g.out, g.obytes), ri = make_rsrc(g.pool_idx, g.ibytes);
     // lane (frow, fk) owns channel frow of a block for the pooled pixels fk*2, fk*2+1 of the 8 in a 16-column block
-    const unsigned ovoff = (unsigned)((fk * 2) * g.Cout + frow) * 2u;          // + w * Cout * 2 via the scalar offset
-    const unsigned ivoff = (frow & 7) == 0 ? (unsigned)((fk * 2) * c8 + (frow >> 3)) * 2u : 0xFFFFFF00u;
+    // the wave's LDS patch behind the two strip buffers: pooled bf16 tile [16 pixels][CB*16 channels] (96-byte rows at
+    // CB = 3, i.e. 16-byte piece c = pixel * 6 + column lies at c * 16), then the position words, one 16-byte row per pixel
+    unsigned char* const ws = smem + 2 * g.buf_bytes + wave * kStemPatch;
+    unsigned char* const wv = ws + (fk * 2) * kStemOutRow + frow * 2;
+    unsigned char* const wi = ws + kStemIdxOff + (fk * 2) * 16 + (frow >> 3) * 2;
+    // store offsets of the pieces a lane carries out (constants of the lane; the tile's position is a scalar offset;
+    // lanes with nothing to store carry an out-of-range offset)
+    const unsigned ovoff0 = (unsigned)((lane / 6) * g.Cout) * 2u + (unsigned)(lane % 6) * 16u;
+    const unsigned ovoff1 = lane < 32 ? (unsigned)(((64 + lane) / 6) * g.Cout) * 2u + (unsigned)((64 + lane) % 6) * 16u : 0xFFFFFF00u;
+    const unsigned ivoff = lane < 16 ? (unsigned)(lane * c8) * 2u : 0xFFFFFF00u;
     auto issue = [&](int s, int buf) {
         const int n = s / spi, oh0 = (s - n * spi) * 4;
         const unsigned src = (unsigned)((n * g.Hs + oh0) * g.Ws) * 32u + (unsigned)lane * 16u;
@@ -2071,12 +2082,8 @@ __global__ void __launch_bounds__(512, 1) stem_pool_kernel(StemPoolArgs g) {
             // lane (r = 0,1 and r = 2,3) and both rows are the two accumulators - the whole window is lane-local.
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
-                // stores: per-lane offsets are constants of the lane, the tile's position is a scalar offset - no
-                // per-store address arithmetic and no branches (lanes that store nothing carry an out-of-range offset)
-                const unsigned q0 = (unsigned)(qrow + cb * 16 + hf * 8);       // first pooled pixel of the 16-column block
 #pragma unroll
                 for (int blk = 0; blk < CB; ++blk) {
-                    const int ch = (cg * CB + blk) * 16;
                     // stage by stage over the 8 values of the block (not value by value): with two waves per SIMD nothing
                     // else hides the latency of a dependent VALU chain
                     float a[2][4], t[2][4], u[2][4];
@@ -2117,8 +2124,8 @@ __global__ void __launch_bounds__(512, 1) stem_pool_kernel(StemPoolArgs g) {
                         const bool m2 = v1 > v0;
                         const float b = m2 ? v1 : v0;
                         const unsigned id = m2 ? (m1 ? 3u : 2u) : (m0 ? 1u : 0u);
-                        __builtin_amdgcn_raw_buffer_store_b16((short)(__builtin_bit_cast(unsigned, b) >> 16), ro, ovoff,
-                                                              ((q0 + w) * (unsigned)g.Cout + (unsigned)ch) * 2u, 0);
+                        *reinterpret_cast<unsigned short*>(wv + (hf * 8 + w) * kStemOutRow + blk * 32) =
+                            (unsigned short)(__builtin_bit_cast(unsigned, b) >> 16);
                         bits |= id << (16 * w);
                     }
                     // 2-bit positions of 8 adjacent channels -> one u16 per pooled pixel: OR over the 8 lanes
@@ -2126,10 +2133,22 @@ __global__ void __launch_bounds__(512, 1) stem_pool_kernel(StemPoolArgs g) {
                     bits |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)bits, 0xB1, 0xF, 0xF, false);    // lane ^ 1
                     bits |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)bits, 0x4E, 0xF, 0xF, false);    // lane ^ 2
                     bits |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)bits, 0x141, 0xF, 0xF, false);   // mirror inside 8 lanes
-                    const unsigned isoff = (q0 * (unsigned)c8 + (unsigned)(ch >> 3)) * 2u;
-                    __builtin_amdgcn_raw_buffer_store_b16((short)bits, ri, ivoff, isoff, 0);
-                    __builtin_amdgcn_raw_buffer_store_b16((short)(bits >> 16), ri, ivoff, isoff + (unsigned)c8 * 2u, 0);
+                    // (all 8 lanes of the group hold the same word now and write it to the same place: no branch)
+                    *reinterpret_cast<unsigned short*>(wi + (hf * 8) * 16 + blk * 4) = (unsigned short)bits;
+                    *reinterpret_cast<unsigned short*>(wi + (hf * 8 + 1) * 16 + blk * 4) = (unsigned short)(bits >> 16);
                 }
+            }
+            // the wave's pooled tile (16 pixels x CB*16 channels) and its position words leave through the wave's own LDS
+            // patch as whole 16-byte pieces: 3 stores per tile instead of 36 two-byte ones (the TA was 69 % busy)
+            {
+                const unsigned so = (unsigned)((qrow + cb * 16) * g.Cout + cg * CB * 16) * 2u;
+                const u32x4 v0 = *reinterpret_cast<const u32x4*>(ws + lane * 16);
+                __builtin_amdgcn_raw_buffer_store_b128(v0, ro, ovoff0, so, 0);
+                const u32x4 v1 = *reinterpret_cast<const u32x4*>(ws + 1024 + (lane & 31) * 16);
+                __builtin_amdgcn_raw_buffer_store_b128(v1, ro, ovoff1, so, 0);
+                const u32x4 vi = *reinterpret_cast<const u32x4*>(ws + kStemIdxOff + (lane & 15) * 16);
+                const unsigned si = (unsigned)((qrow + cb * 16) * c8 + cg * CB * 2) * 2u;
+                __builtin_amdgcn_raw_buffer_store_b96((__attribute__((ext_vector_type(3))) unsigned){vi[0], vi[1], vi[2]}, ri, ivoff, si, 0);
             }
 #ifdef YFS_STEM_TIMING
             {
@@ -2160,7 +2179,7 @@ int launch_stem_pool(const StemPoolArgs& a, hipStream_t stream) {
     g.pieces = (strip_bytes + 1023) / 1024;
     g.buf_bytes = g.pieces * 1024;
     g.nstrips = g.N * (g.OH / 4);
-    const size_t lds = 2 * (size_t)g.buf_bytes;
+    const size_t lds = 2 * (size_t)g.buf_bytes + 8 * kStemPatch;
     auto kern = (g.slope >= 0.0f && g.slope <= 1.0f) ? stem_pool_kernel<3, true> : stem_pool_kernel<3, false>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     YFS_REQUIRE(e == hipSuccess, YFS_ERR_LAUNCH, "yfs_conv2d_stem_fwd_pool_bf16: cannot reserve %zu bytes of LDS", lds);
@@ -2217,7 +2236,7 @@ YFS_API int yfs_conv2d_stem_fwd_pool_bf16(const void* xs, const void* w2, const 
                 "yfs_conv2d_stem_fwd_pool_bf16: conv output %dx%d must be even for the fused 2x2 pool", OH, OW);
     // weight-stationary kernel where its shape assumptions hold (the reference's 448^2 stem does), else the tiled kernel
     if (yfs_knob(YFS_KNOB_STEM_KERNEL) != 1 && Cout == 192 && OH % 4 == 0 && OW % 32 == 0 &&
-        2 * (size_t)((7 * Ws * 32 + 1023) / 1024) * 1024 <= 160 * 1024) {
+        2 * (size_t)((7 * Ws * 32 + 1023) / 1024) * 1024 + 8 * 2048 <= 160 * 1024) {
         StemPoolArgs a = {};
         a.xs = (const bf16_t*)xs; a.w2 = (const bf16_t*)w2; a.bias = bias; a.out = (bf16_t*)y_pooled;
         a.pool_idx = (unsigned short*)pool_idx;
