@@ -197,6 +197,21 @@ def test_conv_fwd_pool_fused_is_bit_identical(n, cin, cout, k, hw):
 
 
 @pytest.mark.gpu
+def test_weight_prep_batch_from_bf16_shadow_matches_fp32_path():
+    """The transposed, tap-reversed dgrad operand made from the optimiser's bf16 shadow (16-byte path of
+    weight_prep_batch_kernel) equals the one made from the fp32 master weight, bit for bit, for several layers in one
+    launch (3x3 and 1x1, Cin != Cout)."""
+    g = torch.Generator().manual_seed(11)
+    ws = [_bf(torch.randn(co_, ci_, k, k, generator=g)) for co_, ci_, k in ((128, 64, 3), (64, 192, 1), (256, 128, 3))]
+    wd = [co.nhwc(w.to(DEV)) for w in ws]
+    ref = [co.weight_prep(w)[1] for w in wd]
+    out = co.weight_prep_batch([(w.to(torch.bfloat16).contiguous(memory_format=co.CL), True, True) for w in wd])
+    for (w16, wt16), r, w in zip(out, ref, wd):
+        assert torch.equal(wt16, r)
+        assert torch.equal(w16.float(), w)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,hw,cout", [(2, 64, 192), (3, 128, 192), (2, 448, 192), (1, 320, 192), (2, 36, 128), (1, 72, 192)])
 def test_stem_fwd_pool_fused_is_bit_identical(n, hw, cout):
     """Stem + pool in one launch == stem forward followed by the pool kernel, bit for bit (pooled values and window
