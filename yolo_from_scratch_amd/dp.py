@@ -49,6 +49,7 @@ class GradComm:
         self._issued = []
         self._c16 = None
         self._host_waits = []      # (work, chunk) of collectives whose completion the host must wait for (gloo)
+        self._deferred = []        # gloo on CUDA tensors: buckets whose collective runs in reduce()
 
     # -- layout -----------------------------------------------------------------------------------
     def attach(self, params, offsets, flat_g, skip_ids=()):
@@ -113,8 +114,9 @@ class GradComm:
           * nccl (= RCCL): the collective is enqueued on RCCL's own stream behind the exchange stream; ``work.wait()``
             only makes the exchange stream wait for it (a stream dependency, no host block), and the 1/world scale is
             queued behind it;
-          * gloo (CPU tensors in tests, CUDA tensors in rehearsals): the Work object is kept and ``reduce`` — called by
-            FlatSGD.step after backward has been enqueued completely — waits for it and applies the scale.
+          * gloo on CPU tensors (tests): the Work object is kept and ``reduce`` — called by FlatSGD.step after backward
+            has been enqueued completely — waits for it and applies the scale;
+          * gloo on CUDA tensors (one-GPU rehearsals): the bucket is only marked; ``reduce`` runs the collectives.
         Order: a bucket is issued when its last parameter reports, and ``reduce`` issues the rest in index order; both are
         functions of the autograd graph alone, which is identical on every rank, so all ranks issue the same sequence."""
         self._issued[idx] = True
@@ -124,6 +126,12 @@ class GradComm:
         if self.stream is None:                               # CPU tensors (gloo tests)
             work = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._host_waits.append((work, chunk, None))
+            return
+        if host_sync:
+            # gloo on CUDA tensors (one-GPU rehearsals): the backend reads the tensor from the host side, so the producing
+            # kernels must have finished first.  Nothing of that may happen inside backward - not even a wait on this
+            # rank's own GPU work - so the bucket is only marked here and ``reduce`` runs the collective.
+            self._deferred.append(idx)
             return
         cur = torch.cuda.current_stream()
         evs = []
@@ -139,15 +147,6 @@ class GradComm:
                 # one staging buffer for all buckets: safe because every use is ordered on the exchange stream
                 buf = self._c16[: hi - lo]
                 buf.copy_(chunk)
-            if host_sync:
-                if self.compress:
-                    buf = chunk.to(torch.bfloat16)            # several host-side collectives in flight: own staging each
-                # gloo reads the tensor from the host side: the producing kernels must have finished first; this wait
-                # is on this rank's own GPU work only, never on a peer
-                self.stream.synchronize()
-                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                self._host_waits.append((work, chunk, buf if self.compress else None))
-                return
             work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             if work is not None:
                 work.wait()                                   # nccl: stream-level wait on the exchange stream
@@ -190,7 +189,30 @@ class GradComm:
             for idx in range(len(self.buckets)):
                 if not self._issued[idx]:
                     self._issue(idx)
-            for work, chunk, staged in self._host_waits:      # gloo only: backward is fully enqueued by now
+            if self._deferred:                                # gloo on CUDA tensors: backward is fully enqueued by now
+                cur = torch.cuda.current_stream()
+                self.stream.wait_stream(cur)
+                for p in _PRODUCERS:
+                    if p.device == cur.device:
+                        self.stream.wait_stream(p)
+                self.stream.synchronize()                     # this rank's own gradients are complete
+                with torch.cuda.stream(self.stream):
+                    works = []
+                    for idx in sorted(self._deferred):        # the same order on every rank
+                        lo, hi = self.buckets[idx]
+                        chunk = flat_g[lo:hi]
+                        buf = chunk.to(torch.bfloat16) if self.compress else chunk
+                        works.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), chunk, buf))
+                    for work, chunk, buf in works:
+                        # waited with the exchange stream current: the backend orders its copy back to the device before
+                        # the stream that is current at wait(), and the scale below must come after that copy
+                        work.wait()
+                        if self.compress:
+                            torch.mul(buf, 1.0 / self.world, out=chunk)
+                        else:
+                            chunk.mul_(1.0 / self.world)
+                self._deferred = []
+            for work, chunk, staged in self._host_waits:      # gloo on CPU tensors
                 if work is not None:
                     work.wait()
                 if self.stream is not None:
