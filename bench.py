@@ -21,6 +21,19 @@ import os
 import sys
 import time
 
+# One process per GPU runs four or more HIP streams here (compute, weight gradients, gradient exchange, the collective
+# backend's own) and the HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues per process (4 on the
+# box).  In the one-GPU rehearsals of the N > 1 path the step stalled with 4 and with 8 queues and
+# ran every time with 16, so multi-rank runs raise a smaller setting to 16 (YFS_KEEP_HW_QUEUES=1 leaves it alone).
+# Read at HIP initialisation, hence set before torch is imported.
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("YFS_KEEP_HW_QUEUES") != "1":
+    try:
+        _q = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    except ValueError:
+        _q = 4
+    if _q < 16:
+        os.environ["GPU_MAX_HW_QUEUES"] = "16"
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -313,6 +326,11 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
+    # Rehearsal of the N > 1 code path on a one-GPU box (YFS_BENCH_ONE_GPU=1): every rank on device 0, gloo instead of
+    # RCCL (two RCCL ranks cannot share a device).  Never used by the driver; its numbers mean nothing.
+    one_gpu = os.environ.get("YFS_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
@@ -321,7 +339,10 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ.get("YFS_BENCH_WATCHDOG_S", "900")), exit=True)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     import yolo_from_scratch_amd as y
     from yolo_from_scratch_amd import dp, synth
@@ -340,6 +361,12 @@ def main():
         memory_format=torch.channels_last)
     target = torch.from_numpy(synth.v1_targets(args.batch, seed=1 + rank)).to(device)
 
+    def note(msg):
+        if one_gpu:
+            print(f"[rehearsal rank {rank}] {msg}", file=sys.stderr, flush=True)
+
+    note("model, optimiser and data ready")
+
     def step():
         opt.zero_grad(set_to_none=True)
         out = model(x)
@@ -355,6 +382,7 @@ def main():
     gc.disable()
     for _ in range(args.warmup):
         step()
+        note("warm-up step done")
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -362,6 +390,9 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+        if one_gpu:
+            torch.cuda.synchronize()
+            note("timed step done")
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
