@@ -337,7 +337,7 @@ def main():
         # A stalled collective must end the run with a diagnosis, not a silent driver timeout: every rank dumps the
         # stacks of all its threads to stderr and exits non-zero if the whole run takes longer than this.
         import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ.get("YFS_BENCH_WATCHDOG_S", "900")), exit=True)
+        faulthandler.dump_traceback_later(int(os.environ.get("YFS_BENCH_WATCHDOG_S", "600")), exit=True)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if one_gpu:
             dist.init_process_group("gloo")
