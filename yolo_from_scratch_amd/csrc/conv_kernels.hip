@@ -640,7 +640,7 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
     if (t < nit) tile(t, std::integral_constant<int, 0>());
     if (wm == 0) bar();   // catch up with waves 4-7: every wave is past its last fragment read after this
 
-    // ---- epilogue: four 64-row slabs of the fp32 tile through LDS, then coalesced 16 B stores (as igemm_kernel) ----
+    // ---- epilogue: the fp32 tile through LDS in 64-row slabs, then coalesced 16 B stores (as igemm_kernel) ----
     // acc[ph][wh][a][b][r] = out[pixel ph*128 + wm*NF*16 + b*16 + (lane&15)][chan wh*128 + wn*32 + a*16 + (lane>>4)*4 + r]
     // with NF = 4 fragments per wave in the first pixel half and FP1 in the second; slab = one wave row of one half
     constexpr int TPR = BN / 8, RPP = NT / TPR;
@@ -653,67 +653,75 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
             sv[j] = g.scale ? g.scale[n0 + ec + j] : 1.0f;
         }
     }
+    // two passes (pixel halves); in each, both wave rows park their slab (<= 64 rows of the fp32 tile) side by side in
+    // LDS (2 x 65 KiB: the ring and the staging state behind it are dead by now), one barrier, then every thread carries
+    // rows of both slabs out: 3 barriers per tile where the four-slab version of this epilogue had 7
+    constexpr int SLAB = 64 * B8_EPI_STRIDE;
+    static_assert(2 * SLAB <= B8_LDS_IG, "epilogue slabs must fit in the kernel's LDS");
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
+    for (int ph = 0; ph < 2; ++ph) {
         constexpr int kNF[2] = {4, FP1};
-        const int NF = kNF[pass >> 1];
-        const int PR = NF * 16;                                       // rows of this slab
-        const int rbase = (pass >> 1) * 128 + (pass & 1) * PR;        // its first row in the tile
-        const int SWEEPS = PR / RPP;
-        if (wm == (pass & 1)) {
+        const int NF = kNF[ph];
+        const int PR = NF * 16;                                       // rows per slab
+        const int rbase = ph * 128;                                   // first tile row of slab 0; slab 1 follows at + PR
+        unsigned char* const myslab = smem + wm * SLAB;
 #pragma unroll
-            for (int wh = 0; wh < 2; ++wh)
+        for (int wh = 0; wh < 2; ++wh)
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        if (b >= NF) continue;
-                        const int ch = wh * 128 + wn * 32 + a * 16 + fk * 4;
-                        *reinterpret_cast<f32x4*>(smem + (b * 16 + frow) * B8_EPI_STRIDE + ch * 4) = acc[pass >> 1][wh][a][b];
-                    }
-        }
+                for (int b = 0; b < 4; ++b) {
+                    if (b >= NF) continue;
+                    const int ch = wh * 128 + wn * 32 + a * 16 + fk * 4;
+                    *reinterpret_cast<f32x4*>(myslab + (b * 16 + frow) * B8_EPI_STRIDE + ch * 4) = acc[ph][wh][a][b];
+                }
         __syncthreads();
         if (EPI == EPI_POOL) {
-            // one item per thread: (window, 8 channels); see igemm_kernel for the pooling rule
+            // one item per thread and slab: (window, 8 channels); see igemm_kernel for the pooling rule
             const int w = tid / TPR, c8 = tid - w * TPR;
-            const int q = ((m0 + rbase) >> 2) + w;
-            if (w < PR / 4 && q * 4 < Mc) {
-                float bvp[8], svp[8];
+            float bvp[8], svp[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    bvp[j] = g.bias[n0 + c8 * 8 + j];
-                    svp[j] = g.scale ? g.scale[n0 + c8 * 8 + j] : 1.0f;
-                }
-                bf16x8 best;
-                unsigned packed = 0;
+            for (int j = 0; j < 8; ++j) {
+                bvp[j] = g.bias[n0 + c8 * 8 + j];
+                svp[j] = g.scale ? g.scale[n0 + c8 * 8 + j] : 1.0f;
+            }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const unsigned char* rp = smem + (4 * w + k) * B8_EPI_STRIDE + c8 * 32;
-                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(rp);
-                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(rp + 16);
-                    const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            for (int sl = 0; sl < 2; ++sl) {
+                const int q = ((m0 + rbase + sl * PR) >> 2) + w;
+                if (w < PR / 4 && q * 4 < Mc) {
+                    bf16x8 best;
+                    unsigned packed = 0;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float tv = __builtin_fmaf(v[j], svp[j], bvp[j]);
-                        const bf16_t yv = (bf16_t)(tv > 0.0f ? tv : tv * g.slope);
-                        if (k == 0 || (float)yv > (float)best[j]) {
-                            best[j] = yv;
-                            packed = (packed & ~(3u << (2 * j))) | ((unsigned)k << (2 * j));
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned char* rp = smem + sl * SLAB + (4 * w + k) * B8_EPI_STRIDE + c8 * 32;
+                        const f32x4 v0 = *reinterpret_cast<const f32x4*>(rp);
+                        const f32x4 v1 = *reinterpret_cast<const f32x4*>(rp + 16);
+                        const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float tv = __builtin_fmaf(v[j], svp[j], bvp[j]);
+                            const bf16_t yv = (bf16_t)(tv > 0.0f ? tv : tv * g.slope);
+                            if (k == 0 || (float)yv > (float)best[j]) {
+                                best[j] = yv;
+                                packed = (packed & ~(3u << (2 * j))) | ((unsigned)k << (2 * j));
+                            }
                         }
                     }
+                    *reinterpret_cast<bf16x8*>(g.out + (long long)q * g.NOUT + n0 + c8 * 8) = best;
+                    g.pool_idx[(long long)q * (g.NOUT / 8) + (n0 >> 3) + c8] = (unsigned short)packed;
                 }
-                *reinterpret_cast<bf16x8*>(g.out + (long long)q * g.NOUT + n0 + c8 * 8) = best;
-                g.pool_idx[(long long)q * (g.NOUT / 8) + (n0 >> 3) + c8] = (unsigned short)packed;
             }
         } else {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                if (p >= SWEEPS) continue;
-                const int row = er + p * RPP;
-                const int m = m0 + rbase + row;
+            for (int p = 0; p < 8; ++p) {
+                const int rr = er + p * RPP;                          // row of the two stacked slabs
+                if (rr >= 2 * PR) continue;
+                const int sl = rr >= PR ? 1 : 0, row = rr - sl * PR;
+                const int m = m0 + rbase + rr;
                 if (m >= Mc) continue;
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(smem + row * B8_EPI_STRIDE + ec * 4);
-                const f32x4 v1 = *reinterpret_cast<const f32x4*>(smem + row * B8_EPI_STRIDE + ec * 4 + 16);
+                const unsigned char* rp = smem + sl * SLAB + row * B8_EPI_STRIDE + ec * 4;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(rp);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(rp + 16);
                 float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                 const long long o = (long long)m * g.NOUT + n0 + ec;
                 if (EPI == EPI_BIAS_LEAKY) {
@@ -733,7 +741,7 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
                 *reinterpret_cast<bf16x8*>(g.out + o) = ov;
             }
         }
-        if (pass < 3) __syncthreads();
+        if (ph == 0) __syncthreads();
     }
 }
 
