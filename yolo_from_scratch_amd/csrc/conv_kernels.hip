@@ -454,9 +454,16 @@ constexpr int B8_EPI_STRIDE = 256 * 4 + 16;   // epilogue: four slabs of <= 64 r
 // FP1 = pixel fragments per wave in the SECOND pixel half-tile: 4 -> 256-row tile, 3 -> 224-row tile (P1 holds 96 rows,
 // phases 3 and 4 run 12 MFMAs).  Every GEMM M of this network is 64 * (7 * 2^k)^2, so 224-row tiles have no ragged edge
 // and their counts (224, 448, 896, ...) fill 256 CUs to 87.5-100 % where 196 / 392 / 784 tiles of 256 rows fill 76.6 %.
+#ifdef YFS_IG8_TIMING
+__device__ long long yfs_ig8_dbg[8];
+#define IG8_T(k) do { if (blockIdx.x == 17 && threadIdx.x == 0) yfs_ig8_dbg[k] = clock64(); } while (0)
+#else
+#define IG8_T(k) do { } while (0)
+#endif
 template <int EPI, int FP1>
 __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
     constexpr int BM = 128 + FP1 * 32, BN = 256, NT = 512;
+    IG8_T(0);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __attribute__((address_space(3))) void* lds_ptr;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -599,6 +606,7 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
     }
     bar();
     if (wm == 1) bar();   // waves 4-7 run one barrier behind waves 0-3 from here on
+    IG8_T(1);
 
     const std::integral_constant<int, 4> F4;
     const std::integral_constant<int, FP1> F1;
@@ -639,6 +647,7 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
     }
     if (t < nit) tile(t, std::integral_constant<int, 0>());
     if (wm == 0) bar();   // catch up with waves 4-7: every wave is past its last fragment read after this
+    IG8_T(2);
 
     // ---- epilogue: the fp32 tile through LDS in 64-row slabs, then coalesced 16 B stores (as igemm_kernel) ----
     // acc[ph][wh][a][b][r] = out[pixel ph*128 + wm*NF*16 + b*16 + (lane&15)][chan wh*128 + wn*32 + a*16 + (lane>>4)*4 + r]
@@ -743,8 +752,20 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
         }
         if (ph == 0) __syncthreads();
     }
+    IG8_T(3);
+#ifdef YFS_IG8_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    IG8_T(4);
+#endif
 }
 
+#ifdef YFS_IG8_TIMING
+}  // namespace
+extern "C" __attribute__((visibility("default"))) int yfs_debug_ig8_times(long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(yfs_ig8_dbg), 8 * sizeof(long long));
+}
+namespace {
+#endif
 template <int EPI, int FP1>
 int launch_igemm8(IgemmArgs& g, hipStream_t s, const char* name) {
     g.mtiles = (int)yfs_cdiv(g.M, 128 + FP1 * 32);
