@@ -816,10 +816,10 @@ int dispatch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
         // L18 403 -> 381, L21 100 -> 94, L24 190 -> 174; dgrad L7 455 -> 426, L18 397 -> 359, L24 206 -> 185, L10 107 -> 102;
         // conv + pool L2 / L7 / L18 1495 -> 1414 in total.  Its main loop runs a 64-deep K-step in ~1.17 us (the rate
         // the chip's clock under MFMA load allows), but every round of 256 tiles pays ~12 us of prologue, epilogue burst
-        // and workgroup turnover, so it needs long K and a grid that fills the CUs: K >= 2304 (1728 for the pool-fused
+        // and workgroup turnover, so it needs long K and a grid that fills the CUs: K >= 1152 (1728 for the pool-fused
         // form) and at least 200 tiles.  224 rows when that needs fewer or shorter rounds.
         const int kdepth = g.KH * g.KW * g.C;
-        if (force == 0 && ok8 && kdepth >= (EPI == EPI_POOL ? 1728 : 2304)) {
+        if (force == 0 && ok8 && kdepth >= (EPI == EPI_POOL ? 1728 : 1152)) {   // (1152: feat.5 forward 158 -> 142 us)
             const long long t224 = yfs_cdiv(g.M, 224) * (g.NOUT / 256), t256 = yfs_cdiv(g.M, 256) * (g.NOUT / 256);
             const double per = kdepth / 64 * 1.17;
             const double c224 = (double)yfs_cdiv(t224, 256) * (12.0 + per * 0.95), c256 = (double)yfs_cdiv(t256, 256) * (12.0 + per);
