@@ -53,6 +53,11 @@ NMS_BYTES_PER_IMG = 108160    # raw head 84,500 + boxes/score/
 # nms: decode launch 104.8 MB + NMS launch 32.1 MB (it re-reads score / class / passing boxes; 4-B reads are over-counted
 # by the doubling, the true figure lies between 126 and 137 MB).
 PMC_TRAFFIC_BYTES = {"nms": 137.0e6, "loss": 1129.5e6, "assign": 264.2e6}
+# MFMA utilisation of the conv kernels from the PMC counters (SQ_VALU_MFMA_BUSY_CYCLES over the active cycles of all SIMDs;
+# rocprofv3 --pmc passes over tools/conv_bench.py, profiles/r02/conv_pmc_summary.txt).  Committed measurements, as above.
+PMC_MFMA_BUSY = {"igemm8_kernel (3x3 forward / dgrad)": [0.52, 0.60], "wgrad8_kernel (3x3 weight gradient)": [0.49, 0.54],
+                 "stem_pool_kernel": 0.50, "igemm_kernel<128,192> (feat.2 dgrad)": 0.47,
+                 "source": "profiles/r02/conv_pmc_summary.txt"}
 
 
 def conv_flops_table(model, batch, hw=448):
@@ -444,6 +449,7 @@ def main():
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
                          "algorithmic_tflop_per_step": round(conv_flops / 1e12, 4), "conv_ms_per_step": round(conv_ms, 3),
+                         "mfma_busy_pmc": PMC_MFMA_BUSY,
                          "measured_over": "%d extra steps with the weight-gradient stream off (non-overlapping "
                                           "brackets); the headline value runs with it on" % rsteps,
                          "kernels": kernels},
