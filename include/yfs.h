@@ -286,6 +286,26 @@ int yfs_linear_wgrad_sgd_bf16(const void *x, const void *dy, int64_t B, int In, 
  * LOWEST-index gt whose centre falls into it: box slot 0 = (xc*S - col, yc*S - row, w, h, 1), one-hot class. */
 int yfs_encode_targets_v1_f32(const float *gt, int64_t N, int G, int S, int B, int C, float *target, void *stream);
 
+/* Segmentation masks -> boxes (the reference's data path: mask_bytes_to_boxes, yolo_toy_regressor_torch.py:98-111 =
+ * skimage label() with full connectivity + regionprops().bbox in label order; the largest-box rule of
+ * get_samples_from_dataset :195-196; box_to_xywh_norm :113-119).  The PNG decode (:99-100) stays with the caller.
+ * mask [N,H,W,CH] u8, a pixel is set when any of its CH channels is non-zero (:101-104).  Per image:
+ *   count [N]               number of 8-connected components
+ *   boxes [N,max_boxes,4]   (x_min, y_min, x_max, y_max), inclusive pixel coordinates, in label order = raster order of
+ *                           each component's first pixel; components past max_boxes are counted but not stored, rows
+ *                           past count are left untouched (boxes may be NULL when max_boxes == 0)
+ *   best_box [N,4]          the box with the largest inclusive area among ALL components, the first one on ties
+ *                           (np.argmax); -1 when the mask is empty (the reference skips such samples, :193-194)
+ *   best_xywh [N,4]         its [xc/W, yc/H, w/W, h/H] computed in fp64 and rounded once to fp32 as :113-119 does
+ *                           (zeros for an empty mask); dims [N,2] = (H_i, W_i) int32 replaces (H, W) in that
+ *                           normalisation for masks that were zero-padded to a common H x W (NULL: H, W)
+ * best_box / best_xywh may be NULL.  H*W <= 2^30.  workspace: yfs_mask_to_boxes_workspace_bytes(N, H, W) bytes of
+ * device memory (about 20 B per pixel), 16-byte aligned like boxes / best_box / best_xywh. */
+size_t yfs_mask_to_boxes_workspace_bytes(int64_t N, int H, int W);
+int yfs_mask_to_boxes_u8(const uint8_t *mask, int64_t N, int H, int W, int CH, const int32_t *dims, int32_t *boxes,
+                         int max_boxes, int32_t *count, int32_t *best_box, float *best_xywh, void *workspace,
+                         size_t workspace_bytes, void *stream);
+
 /* k-means anchor clustering, assignment step (reference: README.md:56 names the feature; nearest code is the k=1
  * median prior estimate_size_priors, practice/yolo_toy_regressor_3_torch.py:278-286).  wh [n,2], anchors [k,2] in
  * the same units, k <= 64 -> assign [n] = argmax_j shape-IoU (ties -> lowest j), best_iou [n] (may be NULL). */

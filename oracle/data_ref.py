@@ -32,6 +32,23 @@ def label_boxes(mask_bin):
     return boxes
 
 
+def target_box(mask_bin, H=None, W=None):
+    """:192-199 for one mask: boxes -> the largest inclusive area (np.argmax: first on ties) -> box_to_xywh_norm
+    (:113-119, fp64 arithmetic, one rounding to fp32).  -> (box, xywh) or (None, None) for an empty mask."""
+    boxes = label_boxes(mask_bin)
+    if not boxes:
+        return None, None
+    areas = [(b[2] - b[0] + 1) * (b[3] - b[1] + 1) for b in boxes]
+    x_min, y_min, x_max, y_max = best = boxes[int(np.argmax(areas))]
+    h0, w0 = np.asarray(mask_bin).shape[:2]
+    H, W = (h0 if H is None else H), (w0 if W is None else W)
+    w = x_max - x_min + 1
+    h = y_max - y_min + 1
+    xc = x_min + (w - 1) / 2.0
+    yc = y_min + (h - 1) / 2.0
+    return best, np.array([xc / W, yc / H, w / W, h / H], dtype=np.float32)
+
+
 def encode_targets_v1(gt, S=7, B=2, C=20):
     gt = np.asarray(gt, np.float32)
     N, G, _ = gt.shape

@@ -1,5 +1,6 @@
-"""Data path after decoding (yolo_toy_regressor_torch.py:98-119, :184-203): mask -> boxes -> [xc,yc,w,h] on the host,
-boxes -> YOLOv1 grid targets on the GPU (bit-exact against the loop oracle and the synthetic generator bench.py uses)."""
+"""Data path after decoding (yolo_toy_regressor_torch.py:98-119, :184-203) on the GPU: masks -> boxes -> largest box as
+[xc,yc,w,h] (csrc/mask_kernels.hip) and boxes -> YOLOv1 grid targets, bit-exact against the loop oracles (and the
+synthetic generator bench.py uses)."""
 import numpy as np
 import pytest
 import torch
@@ -16,22 +17,133 @@ def test_box_to_xywh_norm_known_answers():
     np.testing.assert_array_equal(yd.box_to_xywh_norm((0, 0, 0, 0), 4, 4), np.array([0.0, 0.0, 0.25, 0.25], np.float32))
 
 
-def test_mask_to_boxes_matches_flood_fill_oracle_and_largest_rule():
-    rng = np.random.default_rng(0)
-    for trial in range(5):
-        m = (rng.uniform(size=(40, 56)) < 0.08).astype(np.uint8)
-        m[5:15, 7:30] = 1                       # one large component
-        m[20, 40] = m[21, 41] = 1               # diagonal neighbours: one component under 8-connectivity
-        got, ref = yd.mask_to_boxes(m), data_ref.label_boxes(m)
-        assert sorted(got) == sorted(ref)
-        assert got == ref                       # same (raster first-pixel) order
-        big = yd.largest_box(got)
-        assert big[0] <= 7 and big[2] >= 29 and big[1] <= 5 and big[3] >= 14
-    rgb = np.zeros((8, 8, 3), np.uint8)
-    rgb[2:4, 3:6, 1] = 7
-    assert yd.mask_to_boxes(rgb) == [(3, 2, 5, 3)]
+def _masks(kind, H, W, rng):
+    if kind == "noise":
+        return (rng.uniform(size=(H, W)) < 0.08).astype(np.uint8)
+    if kind == "dense":
+        return (rng.uniform(size=(H, W)) < 0.55).astype(np.uint8)
+    if kind == "checker":                                  # diagonal neighbours only: ONE component under 8-connectivity
+        return ((np.add.outer(np.arange(H), np.arange(W)) & 1) == 0).astype(np.uint8)
+    if kind == "dots":                                     # isolated pixels: the most components a mask can hold
+        m = np.zeros((H, W), np.uint8)
+        m[::2, ::2] = 1
+        return m
+    if kind == "full":
+        return np.full((H, W), 255, np.uint8)
+    if kind == "empty":
+        return np.zeros((H, W), np.uint8)
+    if kind == "spiral":                                   # one long thin component that winds through the whole image
+        m = np.zeros((H, W), np.uint8)
+        t, b, l, r = 0, H - 1, 0, W - 1
+        while t <= b and l <= r:
+            m[t, l:r + 1] = 1
+            m[t:b + 1, r] = 1
+            if b - t >= 2:
+                m[b, l + 2:r + 1] = 1
+            if r - l >= 2 and b - t >= 2:
+                m[t + 2:b + 1, l + 2] = 1
+            t, b, l, r = t + 2, b - 2, l + 2, r - 2
+        return m
+    if kind == "blobs":                                    # what a VOC mask looks like: a few filled shapes + speckle
+        m = (rng.uniform(size=(H, W)) < 0.002).astype(np.uint8)
+        yy, xx = np.mgrid[:H, :W]
+        for _ in range(6):
+            cy, cx, ry, rx = rng.integers(0, H), rng.integers(0, W), rng.integers(3, max(4, H // 4)), rng.integers(3, max(4, W // 4))
+            m |= (((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0).astype(np.uint8)
+        return m
+    raise ValueError(kind)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W", [(40, 56), (64, 64), (33, 129), (7, 5), (1, 300), (300, 1), (96, 200)])
+def test_masks_to_boxes_bit_exact_against_flood_fill_oracle(H, W):
+    """Labels in raster first-pixel order, boxes, the largest-box rule and the fp64 normalisation (:98-119, :195-196):
+    every output equal to the loop oracle, for a batch that mixes all mask kinds."""
+    rng = np.random.default_rng(H * 1000 + W)
+    kinds = ["noise", "dense", "checker", "dots", "full", "empty", "spiral", "blobs", "noise", "blobs"]
+    masks = np.stack([_masks(k, H, W, rng) for k in kinds])
+    cap = ((H + 1) // 2) * ((W + 1) // 2)                   # the "dots" mask: the most components 8-connectivity allows
+    boxes, count, best_box, best_xywh = yd.masks_to_boxes(masks, max_boxes=cap)
+    boxes, count, best_box, best_xywh = boxes.cpu().numpy(), count.cpu().numpy(), best_box.cpu().numpy(), best_xywh.cpu().numpy()
+    for i, k in enumerate(kinds):
+        ref = data_ref.label_boxes(masks[i])
+        assert count[i] == len(ref), k
+        assert [tuple(b) for b in boxes[i, :count[i]].tolist()] == ref, k          # same boxes in the same order
+        rb, rx = data_ref.target_box(masks[i])
+        if rb is None:
+            assert tuple(best_box[i]) == (-1, -1, -1, -1) and not best_xywh[i].any()
+        else:
+            assert tuple(best_box[i]) == rb, k
+            np.testing.assert_array_equal(best_xywh[i], rx)
+
+
+@pytest.mark.gpu
+def test_masks_to_boxes_channels_truncation_dims_and_single_mask_surface():
+    rng = np.random.default_rng(5)
+    rgb = np.zeros((3, 24, 40, 3), np.uint8)
+    rgb[0, 2:4, 3:6, 1] = 7                                 # set in one channel only
+    rgb[1, 5, 5, 0] = rgb[1, 6, 6, 2] = 1                   # diagonal neighbours through different channels
+    rgb[2] = (rng.uniform(size=(24, 40, 3)) < 0.03) * 200
+    boxes, count, best_box, best_xywh = yd.masks_to_boxes(rgb, max_boxes=4, dims=[[24, 40], [48, 80], [24, 40]])
+    assert boxes.shape == (3, 4, 4)
+    assert count[:2].tolist() == [1, 1] and boxes[0, 0].tolist() == [3, 2, 5, 3] and boxes[1, 0].tolist() == [5, 5, 6, 6]
+    flat = rgb[2].any(axis=2)
+    ref = data_ref.label_boxes(flat)
+    assert int(count[2]) == len(ref) > 4                    # counted beyond max_boxes, the first four stored
+    assert [tuple(b) for b in boxes[2].cpu().tolist()] == ref[:4]
+    assert tuple(best_box[2].tolist()) == data_ref.target_box(flat)[0]              # ... and the largest taken over ALL of them
+    np.testing.assert_array_equal(best_xywh[1].cpu().numpy(), data_ref.target_box(rgb[1].any(axis=2), H=48, W=80)[1])
+    # the reference's per-sample surface
+    assert yd.mask_to_boxes(rgb[0]) == [(3, 2, 5, 3)]
+    assert yd.mask_to_boxes(flat.astype(np.uint8)) == ref
+    assert yd.mask_to_boxes(torch.from_numpy(rgb[2]).cuda()) == ref
     assert yd.mask_to_target_box(np.zeros((8, 8), np.uint8)) is None
-    np.testing.assert_array_equal(yd.mask_to_target_box(rgb), yd.box_to_xywh_norm((3, 2, 5, 3), 8, 8))
+    np.testing.assert_array_equal(yd.mask_to_target_box(rgb[0]), yd.box_to_xywh_norm((3, 2, 5, 3), 24, 40))
+    dots = _masks("dots", 30, 30, rng)
+    assert len(yd.mask_to_boxes(dots)) == 225               # more components than the first guess of 64: asked again
+    with pytest.raises(yd.L.YfsError):
+        yd.masks_to_boxes(torch.zeros(2, 4, 4, dtype=torch.float32, device="cuda"))
+
+
+@pytest.mark.gpu
+def test_masks_to_boxes_voc_sized_batch_against_scipy_and_rerun():
+    """375 x 500 masks (the VOC size), batch 16: against scipy.ndimage (an independent labelling; the flood-fill oracle
+    needs seconds per mask at this size and checks two of them), and bit-identical on a second run."""
+    from scipy import ndimage
+    rng = np.random.default_rng(11)
+    masks = np.stack([_masks(k, 375, 500, rng) for k in ["blobs"] * 10 + ["noise", "spiral", "checker", "dense", "full", "empty"]])
+    dev = torch.from_numpy(masks).cuda()
+    out1 = yd.masks_to_boxes(dev, max_boxes=4096)
+    out2 = yd.masks_to_boxes(dev, max_boxes=4096)
+    for a, b in zip(out1[1:], out2[1:]):
+        assert torch.equal(a, b)
+    boxes, count = out1[0].cpu().numpy(), out1[1].cpu().numpy()
+    for i in range(len(masks)):
+        lab, n = ndimage.label(masks[i], structure=np.ones((3, 3), np.int32))
+        assert count[i] == n
+        ref = [(sl[1].start, sl[0].start, sl[1].stop - 1, sl[0].stop - 1) for sl in ndimage.find_objects(lab)]
+        k = min(n, 4096)
+        assert [tuple(b) for b in boxes[i, :k].tolist()] == ref[:k]
+        assert torch.equal(out1[0][i, :k], out2[0][i, :k])
+    for i in (0, 11):
+        rb, rx = data_ref.target_box(masks[i])
+        assert tuple(out1[2][i].tolist()) == rb
+        np.testing.assert_array_equal(out1[3][i].cpu().numpy(), rx)
+
+
+def test_flood_fill_oracle_known_answers():
+    """The oracle itself on hand-checked masks (8-connectivity, label order, inclusive boxes, first-largest rule)."""
+    m = np.zeros((6, 8), np.uint8)
+    m[0, 5:7] = 1                     # component 1: first pixel (0, 5)
+    m[1, 0] = m[2, 1] = m[3, 0] = 1   # component 2: a diagonal chain, first pixel (1, 0)
+    m[4:6, 3:5] = 1                   # component 3: 2 x 2 block, first pixel (4, 3)
+    assert data_ref.label_boxes(m) == [(5, 0, 6, 0), (0, 1, 1, 3), (3, 4, 4, 5)]
+    box, xywh = data_ref.target_box(m)
+    assert box == (0, 1, 1, 3)        # areas 2, 6, 4
+    np.testing.assert_array_equal(xywh, np.array([0.5 / 8, 2.0 / 6, 2 / 8, 3 / 6], np.float32))
+    m[4:6, 3:6] = 1                   # now 2 x 3 = 6 as well: the FIRST of the two largest stays
+    assert data_ref.target_box(m)[0] == (0, 1, 1, 3)
+    assert data_ref.target_box(np.zeros((3, 3))) == (None, None)
 
 
 def test_encode_oracle_equals_synthetic_generator():

@@ -1,28 +1,65 @@
-"""Host side of the reference's data path after decoding: segmentation mask -> boxes ->
-normalised [xc, yc, w, h] -> YOLOv1 grid targets (the last step on the GPU).
+"""The reference's data path after decoding: segmentation mask -> boxes -> normalised
+[xc, yc, w, h] -> YOLOv1 grid targets, on the GPU.
 
 Mirrors ``yolo_toy_regressor_torch.py``: ``mask_bytes_to_boxes`` (:98-111, without the PIL decode: takes the mask
-array; the reference labels with skimage's default full connectivity, done here with scipy.ndimage and a 3x3
-structure), ``box_to_xywh_norm`` (:113-119), the largest-box rule of ``get_samples_from_dataset`` (:194-199).
-The VOC parquet files, PIL decoding and resizing stay with the caller (no dataset ships with the reference)."""
+array; the reference labels with skimage's default full connectivity — here ``csrc/mask_kernels.hip``, a union-find
+over the pixels of the whole batch), ``box_to_xywh_norm`` (:113-119), the largest-box rule of
+``get_samples_from_dataset`` (:194-199).  The VOC parquet files, PIL decoding and resizing stay with the caller (no
+dataset ships with the reference).  There is no host implementation: masks given as numpy arrays are uploaded."""
 import numpy as np
 import torch
 
 from . import _lib as L
 
+_ws = {}
+
+
+def masks_to_boxes(masks, max_boxes=64, dims=None):
+    """masks: [N,H,W] or [N,H,W,CH] uint8/bool, CUDA tensor (or numpy array: uploaded), non-zero = object.
+    -> (boxes int32 [N,max_boxes,4] as (x_min, y_min, x_max, y_max) in label order, rows past count undefined;
+        count int32 [N]; best_box int32 [N,4] (-1 for an empty mask); best_xywh fp32 [N,4]) as :98-119 and :195-196.
+    ``dims`` [N,2] = (H_i, W_i): the original sizes of masks that were zero-padded to a common H x W."""
+    if not torch.is_tensor(masks):
+        masks = torch.from_numpy(np.ascontiguousarray(masks)).cuda()
+    L.require_cuda(masks)
+    if masks.dtype == torch.bool:
+        masks = masks.to(torch.uint8)
+    if masks.dtype != torch.uint8 or masks.dim() not in (3, 4):
+        raise L.YfsError(f"masks_to_boxes: expected uint8 [N,H,W] or [N,H,W,CH], got {masks.dtype} {tuple(masks.shape)}")
+    masks = masks.contiguous()
+    n, h, w = masks.shape[:3]
+    ch = masks.shape[3] if masks.dim() == 4 else 1
+    dev = masks.device
+    if dims is not None:
+        dims = torch.as_tensor(dims, dtype=torch.int32).to(dev).contiguous()
+        if tuple(dims.shape) != (n, 2):
+            raise L.YfsError(f"masks_to_boxes: dims must be [N, 2], got {tuple(dims.shape)}")
+    boxes = torch.empty(n, max(max_boxes, 1), 4, device=dev, dtype=torch.int32)
+    count = torch.empty(n, device=dev, dtype=torch.int32)
+    best_box = torch.empty(n, 4, device=dev, dtype=torch.int32)
+    best_xywh = torch.empty(n, 4, device=dev, dtype=torch.float32)
+    nbytes = L.lib().yfs_mask_to_boxes_workspace_bytes(L.i64(n), L.c_int(h), L.c_int(w))
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _ws[key] = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    L.check(L.lib().yfs_mask_to_boxes_u8(L.ptr(masks), L.i64(n), L.c_int(h), L.c_int(w), L.c_int(ch), L.ptr(dims), L.ptr(boxes),
+                                         L.c_int(max_boxes), L.ptr(count), L.ptr(best_box), L.ptr(best_xywh), L.ptr(ws),
+                                         L.c_size(nbytes), L.stream()), "yfs_mask_to_boxes_u8")
+    return boxes[:, :max_boxes], count, best_box, best_xywh
+
 
 def mask_to_boxes(mask):
-    """mask: [H,W] or [H,W,ch] array, non-zero = object.  -> list of (x_min, y_min, x_max, y_max), inclusive pixel
-    coordinates, one per 8-connected component, in label (raster first-pixel) order — as :98-111."""
-    from scipy import ndimage
-    arr = np.asarray(mask)
-    mask_bin = np.any(arr != 0, axis=2) if arr.ndim == 3 else (arr != 0)
-    lab, n = ndimage.label(mask_bin, structure=np.ones((3, 3), np.int32))
-    boxes = []
-    for sl in ndimage.find_objects(lab):
-        (r0, r1), (c0, c1) = (sl[0].start, sl[0].stop), (sl[1].start, sl[1].stop)
-        boxes.append((c0, r0, c1 - 1, r1 - 1))
-    return boxes
+    """One mask ([H,W] or [H,W,ch], numpy or CUDA tensor) -> list of (x_min, y_min, x_max, y_max), inclusive pixel
+    coordinates, one per 8-connected component, in label (raster first-pixel) order — the return value of :98-111."""
+    m = mask if torch.is_tensor(mask) else np.asarray(mask)
+    cap = 64
+    while True:
+        boxes, count, _, _ = masks_to_boxes(m[None], max_boxes=cap)
+        k = int(count[0])
+        if k <= cap:
+            return [tuple(b) for b in boxes[0, :k].cpu().tolist()]
+        cap = k
 
 
 def box_to_xywh_norm(box, H, W):
@@ -43,11 +80,11 @@ def largest_box(boxes):
 
 def mask_to_target_box(mask):
     """mask -> [xc, yc, w, h] float32 of its largest component, or None when the mask is empty (:190-199)."""
-    boxes = mask_to_boxes(mask)
-    if not boxes:
+    m = mask if torch.is_tensor(mask) else np.asarray(mask)
+    _, count, _, xywh = masks_to_boxes(m[None], max_boxes=0)
+    if int(count[0]) == 0:
         return None
-    H, W = np.asarray(mask).shape[:2]
-    return box_to_xywh_norm(largest_box(boxes), H, W)
+    return xywh[0].cpu().numpy()
 
 
 def encode_targets_v1(gt, S=7, B=2, C=20):
