@@ -267,6 +267,37 @@ def assign_bench(device, N=8192, S=13, G=32):
             "roofline": _hbm_record(N * ASSIGN_BYTES_PER_IMG, ms, PMC_TRAFFIC_BYTES["assign"] if (N, S, G) == (8192, 13, 32) else None)}
 
 
+def mask_boxes_bench(device, N=64, H=375, W=500, cpu_sample=6):
+    """The reference's mask -> component boxes -> largest box step on VOC-sized synthetic masks:
+    a few filled shapes plus speckle.  Integer work bound by dependent L2 round trips and atomics (DESIGN.md §4 set 5), so
+    it carries no HBM fraction; the oracle's flood fill on the host is timed beside it on a few masks."""
+    from yolo_from_scratch_amd import data as yd
+    rng = np.random.default_rng(0)
+    yy, xx = np.mgrid[:H, :W]
+    masks = np.zeros((N, H, W), np.uint8)
+    for i in range(N):
+        m = rng.uniform(size=(H, W)) < 0.002
+        for _ in range(6):
+            cy, cx, ry, rx = rng.integers(0, H), rng.integers(0, W), rng.integers(3, H // 4), rng.integers(3, W // 4)
+            m |= ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0
+        masks[i] = m
+    dev = torch.from_numpy(masks).to(device)
+    out = {}
+    ms = _time_ms(lambda: out.__setitem__("r", yd.masks_to_boxes(dev, max_boxes=1024)), 20)
+    rec = {"metric": "mask -> boxes -> largest box, masks/sec (%d x %d x 1 u8, batch %d)" % (H, W, N),
+           "value": round(N / (ms * 1e-3), 1), "unit": "masks/s", "ms_per_batch": round(ms, 4), "dtype": "u8/int32",
+           "components_per_mask": round(float(out["r"][1].float().mean()), 1)}
+    if cpu_sample:
+        from oracle import data_ref
+        t0 = time.perf_counter()
+        for i in range(cpu_sample):
+            data_ref.target_box(masks[i])
+        dt = time.perf_counter() - t0
+        rec["cpu_baseline"] = {"value": round(cpu_sample / dt, 2), "unit": "masks/s", "cores": 1, "kind": "port",
+                               "sample": f"{cpu_sample} of the same masks (oracle/data_ref.py flood fill, pure Python) on {_cpu_model()}"}
+    return rec
+
+
 def measured_ceilings(device):
     """What this box sustains, next to the vendor peaks the roofline fractions are priced against."""
     import ctypes
@@ -460,6 +491,7 @@ def main():
                 rec["nms"]["cpu_baseline"] = cpu_baseline_nms()
             rec["loss"] = loss_bench(device)
             rec["assign"] = assign_bench(device)
+            rec["mask_boxes"] = mask_boxes_bench(device, cpu_sample=0 if args.no_cpu_baseline else 6)
             if not args.no_cpu_baseline:
                 rec["loss"]["cpu_baseline"] = cpu_baseline_loss()
                 rec["assign"]["cpu_baseline"] = cpu_baseline_assign()
