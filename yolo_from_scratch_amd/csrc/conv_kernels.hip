@@ -1842,6 +1842,11 @@ int wgrad_common(const char* fn, const void* x, const void* dz, float* dw, float
     YFS_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, YFS_ERR_WORKSPACE, "%s: workspace must be 16-byte aligned", fn);
     WgradArgs g = {};
     g.dz = (const bf16_t*)dz; g.x = (const bf16_t*)x; g.partial = (float*)workspace;
+    // One split and nothing to add to: the single partial slab IS the gradient (same [Cout][taps][Cin] layout), so the
+    // kernel writes it straight into dw and the reduction pass below only sums the bias-gradient rows (feat.24-27:
+    // 37.7 MB written once instead of written, read and written again).
+    const bool direct = p.splits == 1 && !accumulate;
+    if (direct) g.partial = dw;
     g.dbpart = db ? (float*)((unsigned char*)workspace + p.partial_bytes) : nullptr;
     g.H = H; g.W = W; g.Cin = Cin; g.OH = OH; g.OW = OW; g.Cout = Cout; g.KH = KH; g.KW = KW; g.PS = PS; g.stride = stride; g.pad = pad;
     g.M = (int)M;
@@ -1876,9 +1881,11 @@ int wgrad_common(const char* fn, const void* x, const void* dz, float* dw, float
     const int G = (p.splits >= 32 && n4 * 4 < 65536 * 4) ? 16 : ((p.splits >= 8 && n4 < 65536 * 4) ? 4 : 1);
     long long rblk = yfs_cdiv(n4, kThreads / G);
     if (rblk > 4096) rblk = 4096;
+    if (direct) rblk = 0;
     const float4* part4 = (const float4*)workspace;
     const float* dbp = db ? (const float*)((unsigned char*)workspace + p.partial_bytes) : nullptr;
     const int cblk = db ? (int)yfs_cdiv(Cout, 16) : 0;
+    if (rblk + cblk == 0) return YFS_OK;
     const dim3 grid((unsigned)(rblk + cblk));
     if (G == 16)
         splitk_reduce_kernel<16><<<grid, dim3(kThreads), 0, s>>>(part4, p.splits, n4, (float4*)dw, accumulate, (int)rblk, dbp,
