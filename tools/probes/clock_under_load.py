@@ -3,7 +3,8 @@
 is the 2.4 GHz the dense-MFMA peak is quoted at reachable under the conv kernels' load?
     python tools/probes/clock_under_load.py [seconds per load]
 Loads: idle, register-only MFMA loop (yfs_probe_mfma_bf16), feat.18 forward (igemm8_kernel), feat.18 weight gradient
-(wgrad8_kernel), a device-to-device copy (HBM only)."""
+(wgrad8_kernel), a device-to-device copy (HBM only); the forward also on an all-zero input (same instructions, no toggling
+operands: what the data itself costs in power)."""
 import json, os, subprocess, sys, threading, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -27,7 +28,9 @@ def mfma():
     L.check(L.lib().yfs_probe_mfma_bf16(L.c_int(20000), L.c_int(1024), ctypes.byref(flop), L.ptr(scratch), L.stream()), "probe")
 
 
+x0 = torch.zeros_like(x)
 loads = [("idle", None), ("mfma register loop", mfma), ("feat.18 forward (igemm8)", lambda: co.conv_fwd(x, w16, b, 1)),
+         ("feat.18 forward, x = 0", lambda: co.conv_fwd(x0, w16, b, 1)),
          ("feat.18 wgrad (wgrad8)", lambda: co.conv_wgrad(x, dz, 3, 1)), ("d2d copy 256 MiB", lambda: big2.copy_(big))]
 
 
