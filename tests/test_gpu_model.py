@@ -373,3 +373,44 @@ def test_wrong_resolution_raises_the_references_shape_error():
     model = ym.YoloRegressorModel(head_out=4, image_size=64).to(DEV)          # fc.1 sized for 64x64 inputs (1024 features)
     with pytest.raises(RuntimeError, match=r"mat1 and mat2 shapes cannot be multiplied \(2x4096 and 1024x4096\)"):
         model(torch.rand(2, 3, 128, 128, device=DEV))
+
+
+@pytest.mark.parametrize("size,backward", [(320, True), (416, False), (608, False)])
+def test_backbone_runs_at_every_multi_scale_resolution(size, backward):
+    """BASELINE configs[4] cycles the input over 320 ... 608 (multiples of 32): the convolutional part of the model is
+    resolution-free, so ``feat`` must give the reference's result at each of them (only ``fc`` is sized for one image
+    size, test_wrong_resolution_raises_the_references_shape_error).  CPU chain of the same torch ops with the activations
+    rounded to bf16 where the GPU chain stores them; at 320 also the weight and bias gradients."""
+    torch.manual_seed(0)
+    net = ym.YoloRegressorModel(head_out=4, image_size=64).feat
+    with torch.no_grad():
+        for p in net.parameters():
+            p.copy_(_bf(p))
+    ref_params = {k: v.detach().clone().contiguous().requires_grad_(backward) for k, v in net.state_dict().items()}
+    net = net.to(DEV)
+    x = _bf(torch.rand(2, 3, size, size, generator=torch.Generator().manual_seed(size)))
+    h = x
+    for i, cfg in enumerate(model_ref.FEAT_CFG):
+        if cfg == "P":
+            h = F.max_pool2d(h, 2, 2)
+        else:
+            h = _RoundBf16.apply(model_ref.conv_block(h, ref_params[f"{i}.0.weight"], ref_params[f"{i}.0.bias"], cfg[3]))
+    if backward:
+        out = net(x.to(DEV))
+    else:
+        with torch.no_grad():
+            out = net(x.to(DEV))
+    assert tuple(out.shape) == tuple(h.shape) == (2, 1024, (size // 32 + 1) // 2, (size // 32 + 1) // 2)
+    assert _rel(out, h) < 1e-2
+    if backward:
+        gy = _bf(torch.randn(h.shape, generator=torch.Generator().manual_seed(2)) * 1e-2)
+        out.backward(gy.to(DEV))
+        h.backward(gy)
+        # Through 24 randomly initialised layers the gradient is chaotic in the forward rounding: two CPU runs of this
+        # chain whose pre-activations differ by 1e-3 relative noise disagree by 2.7 % at feat.27 and 77 % at feat.0
+        # (LeakyReLU masks and pool winners of near-tie elements flip).  So the layers next to the output are held to
+        # the per-op tolerance and the rest to "same direction, same size"; the per-layer kernels are pinned one by
+        # one in test_gpu_conv.py and the short chain above.
+        for k, p in net.named_parameters():
+            r = _rel(p.grad, ref_params[k].grad)
+            assert torch.isfinite(p.grad).all() and r < (3e-2 if int(k.split(".")[0]) >= 25 else 0.8), (k, r)
