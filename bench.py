@@ -315,9 +315,21 @@ def measured_ceilings(device):
         L.check(L.lib().yfs_probe_mfma_bf16(L.c_int(iters), L.c_int(blocks), ctypes.byref(flop), L.ptr(scratch), L.stream()),
                 "yfs_probe_mfma_bf16")
     ms = _time_ms(run, 5, warm=2)
-    return {"hbm_copy_GBps": round(hbm, 1), "mfma_bf16_TFLOPs": round(flop.value / (ms * 1e-3) / 1e12, 1),
+    ones = flop.value / (ms * 1e-3) / 1e12
+    rnd = {}
+    for shape, label in ((0, "16x16x32"), (1, "32x32x16")):
+        def run_rnd(shape=shape):
+            L.check(L.lib().yfs_probe_mfma_bf16_ex(L.c_int(shape), L.c_int(1), L.c_int(20000), L.c_int(1024), ctypes.byref(flop),
+                                                   L.ptr(scratch), L.stream()), "yfs_probe_mfma_bf16_ex")
+        ms = _time_ms(run_rnd, 15, warm=15)      # ~0.2 s of load before the timed launches: the clock has settled
+        rnd[label] = round(flop.value / (ms * 1e-3) / 1e12, 1)
+    return {"hbm_copy_GBps": round(hbm, 1), "mfma_bf16_TFLOPs": round(ones, 1),
+            "mfma_bf16_random_operands_TFLOPs": rnd,
             "note": "device-to-device copy of 1 GiB (read + write bytes); register-only v_mfma_f32_16x16x32_bf16 loop, "
-                    "8 workgroups x 4 waves per CU, at the clock the chip holds under that load"}
+                    "8 workgroups x 4 waves per CU, at the clock the chip holds under that load; the same loop with "
+                    "operands that change from one MFMA to the next (pseudo-random bf16 in +-[0.5, 2)): the matrix pipe "
+                    "alone, fed from registers, is power-limited on switching data (DESIGN.md set 1, "
+                    "profiles/r02/clock_under_load.txt)"}
 
 
 def _cpu_model():

@@ -316,6 +316,10 @@ int yfs_anchor_assign_f32(const float *wh, int64_t n, const float *anchors, int 
  * 16 MFMAs of 16x16x32) and return the FLOPs it performs in *flop_out; the caller times it.  scratch: >= 4 bytes of
  * device memory (never written in practice).  bench.py prints the resulting rate next to the vendor peak. */
 int yfs_probe_mfma_bf16(int iters, int blocks, double *flop_out, void *scratch, void *stream);
+/* The same loop with operands that change from one MFMA to the next (toggling != 0: eight pseudo-random fragments per
+ * side; 0: all ones) on the 16x16x32 (shape 0) or 32x32x16 (shape 1) instruction: what the matrix pipe alone sustains
+ * when its inputs switch the way real data does (tools/probes/clock_under_load.py). */
+int yfs_probe_mfma_bf16_ex(int shape, int toggling, int iters, int blocks, double *flop_out, void *scratch, void *stream);
 
 #ifdef __cplusplus
 }

@@ -28,8 +28,20 @@ def mfma():
     L.check(L.lib().yfs_probe_mfma_bf16(L.c_int(20000), L.c_int(1024), ctypes.byref(flop), L.ptr(scratch), L.stream()), "probe")
 
 
+def mfma_ex(shape, toggling):
+    def run():
+        L.check(L.lib().yfs_probe_mfma_bf16_ex(L.c_int(shape), L.c_int(toggling), L.c_int(20000), L.c_int(1024), ctypes.byref(flop),
+                                               L.ptr(scratch), L.stream()), "probe_ex")
+    return run
+
+
 x0 = torch.zeros_like(x)
-loads = [("idle", None), ("mfma register loop", mfma), ("feat.18 forward (igemm8)", lambda: co.conv_fwd(x, w16, b, 1)),
+MFMA_FLOP = 1024 * 4.0 * 20000 * 16.0 * (2.0 * 16 * 16 * 32)
+L18_FLOP = 2.0 * 64 * 28 * 28 * 1024 * 9 * 512
+FLOPS = {"mfma": MFMA_FLOP, "feat.18": L18_FLOP}
+loads = [("idle", None), ("mfma register loop", mfma),
+         ("mfma 16x16x32, operands = 1", mfma_ex(0, 0)), ("mfma 16x16x32, random operands", mfma_ex(0, 1)),
+         ("mfma 32x32x16, operands = 1", mfma_ex(1, 0)), ("mfma 32x32x16, random operands", mfma_ex(1, 1)), ("feat.18 forward (igemm8)", lambda: co.conv_fwd(x, w16, b, 1)),
          ("feat.18 forward, x = 0", lambda: co.conv_fwd(x0, w16, b, 1)),
          ("feat.18 wgrad (wgrad8)", lambda: co.conv_wgrad(x, dz, 3, 1)), ("d2d copy 256 MiB", lambda: big2.copy_(big))]
 
@@ -75,6 +87,7 @@ for name, fn in loads:
                     except ValueError:
                         pass
     fmt = lambda a: f"{min(a):.0f}-{max(a):.0f} (mean {sum(a) / len(a):.0f})" if a else "n/a"
-    print(f"{name:28s} {n / dt if fn else 0:9.1f} launches/s  sclk MHz {fmt(sclk)}  power W {fmt(power)}  [{len(out)} samples]", flush=True)
+    fl = next((v for k, v in FLOPS.items() if name.startswith(k)), 0.0)
+    print(f"{name:32s} {n / dt if fn else 0:9.1f} launches/s {fl * n / dt / 1e12 if fn else 0:7.0f} TFLOP/s  sclk MHz {fmt(sclk)}  power W {fmt(power)}  [{len(out)} samples]", flush=True)
 if out:
     print("last raw sample:", json.dumps(out[-1])[:600])
