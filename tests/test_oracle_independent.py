@@ -187,3 +187,25 @@ def test_c_oracle_assignment_masks_vs_brute_force_including_crowding():
     np.testing.assert_array_equal(o0, o1)
     np.testing.assert_array_equal(i0, i1)
     assert o1.sum() > 0 and i1.sum() > 0
+
+
+def test_flood_fill_oracle_vs_scipy_labelling():
+    """oracle/data_ref.label_boxes (flood fill in raster order) against scipy.ndimage.label + find_objects with the full
+    3x3 structure — an independent implementation of what skimage.measure.label(connectivity=2) + regionprops().bbox
+    compute (the reference's :105-110; skimage itself is not installed here): same components, same order, same boxes."""
+    from scipy import ndimage
+    from oracle import data_ref
+    rng = np.random.default_rng(3)
+    for trial in range(12):
+        H, W = int(rng.integers(1, 70)), int(rng.integers(1, 90))
+        m = (rng.uniform(size=(H, W)) < rng.choice([0.05, 0.3, 0.6, 0.9])).astype(np.uint8)
+        lab, n = ndimage.label(m, structure=np.ones((3, 3), np.int32))
+        ref = [(sl[1].start, sl[0].start, sl[1].stop - 1, sl[0].stop - 1) for sl in ndimage.find_objects(lab)]
+        assert data_ref.label_boxes(m) == ref
+        box, xywh = data_ref.target_box(m)
+        if n == 0:
+            assert box is None
+        else:
+            areas = [(b[2] - b[0] + 1) * (b[3] - b[1] + 1) for b in ref]
+            assert box == ref[int(np.argmax(areas))]
+            assert xywh.dtype == np.float32 and (xywh > 0).all() and (xywh[2:] <= 1).all()
