@@ -379,9 +379,18 @@ def main():
     one_gpu = os.environ.get("YFS_BENCH_ONE_GPU") == "1"
     if one_gpu:
         local_rank = 0
+    # YFS_BENCH_FORCE_DP=1 (rehearsal, never used by the driver): take the N > 1 code path with a group of ONE rank on real
+    # RCCL: process-group set-up as below, the full gradient exchange (dp.GradComm(force=True)), barriers, the MAX
+    # all-reduce of the time.  The exchange of one rank changes no value; its cost is the machinery itself.
+    force_dp = os.environ.get("YFS_BENCH_FORCE_DP") == "1" and world == 1
+    multi = world > 1 or force_dp
+    if force_dp:
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if multi:
         # A stalled collective must end the run with a diagnosis, not a silent driver timeout: every rank dumps the
         # stacks of all its threads to stderr and exits non-zero if the whole run takes longer than this.
         import faulthandler
@@ -400,7 +409,7 @@ def main():
     torch.manual_seed(0)
     model = ym.YoloRegressorModel(head_out=7 * 7 * 30).to(device)
     model.train()                                    # Dropout(0.2) active, as in the reference's train loop
-    comm = dp.GradComm(world, compress_bf16=args.compress_bf16) if world > 1 else None
+    comm = dp.GradComm(world, compress_bf16=args.compress_bf16, force=force_dp) if multi else None
     opt = yt.FlatSGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=5e-4, max_norm=1.0, comm=comm)
     dp.broadcast_parameters(opt)
     crit = y.YoloV1Loss(7, 2, 20)
@@ -432,7 +441,7 @@ def main():
         step()
         note("warm-up step done")
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -442,7 +451,7 @@ def main():
             torch.cuda.synchronize()
             note("timed step done")
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -463,7 +472,7 @@ def main():
     timers.remove()
     ym._TWO_STREAMS = two
     gc.enable()
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
@@ -486,7 +495,7 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "grad_allreduce": (("bf16" if args.compress_bf16 else "fp32") +
                                           (" buckets; fc.1 as all-gathered gradient factors" if opt._defer else ""))
-                       if world > 1 else None},
+                       if multi else None},
             "final_loss": round(final_loss, 5),
             "roofline": {"bound": "mfma", "kernel": "conv implicit-GEMM set (igemm_kernel / igemm8_kernel / stem_pool_kernel fwd+dgrad, wgrad_kernel / wgrad8_kernel)",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
@@ -512,8 +521,10 @@ def main():
             del model, opt
             torch.cuda.empty_cache()
             rec["cpu_baseline"] = cpu_baseline_train()
+        if force_dp:
+            rec["rehearsal"] = "YFS_BENCH_FORCE_DP=1: one-rank RCCL group with the full gradient exchange forced on"
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
         import faulthandler

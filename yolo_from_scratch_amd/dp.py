@@ -35,9 +35,13 @@ def register_producer_stream(stream):
 
 class GradComm:
     def __init__(self, world_size=None, bucket_bytes=32 << 20, compress_bf16=False, group=None,
-                 tail_bytes=16 << 20, tail_bucket_bytes=4 << 20):
+                 tail_bytes=16 << 20, tail_bucket_bytes=4 << 20, force=False):
+        """``force``: run the whole exchange (buckets, side stream, collectives, factor gather) even in a group of ONE
+        rank, where it must change nothing — the only way to execute the RCCL code path on a one-GPU box
+        (tests/test_zy_rccl_one_rank.py)."""
         self.group = group
         self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.active = self.world > 1 or force
         self.bucket_bytes = bucket_bytes
         self.tail_bytes, self.tail_bucket_bytes = tail_bytes, min(tail_bucket_bytes, bucket_bytes)
         self.compress = compress_bf16
@@ -96,7 +100,7 @@ class GradComm:
 
     def notify(self, param):
         """Called by the autograd nodes right after they enqueue the kernel that writes param's gradient."""
-        if self.world <= 1:
+        if not self.active:
             return
         idx = self.param_bucket.get(id(param))
         if idx is None or self._issued[idx]:
@@ -160,7 +164,7 @@ class GradComm:
         [world*B, ...].  For fc.1 that is 6.9 MB per rank on the wire instead of an 807 MB all-reduce, and the averaged
         gradient sum_r dy_r^T x_r / world is formed inside the fused wgrad + SGD kernel, never in memory.  Runs on the
         exchange stream; ``reduce`` (called by FlatSGD.step) makes the compute stream wait for it."""
-        if self.world <= 1:
+        if not self.active:
             return x16, dy16
         outs = []
         if self.stream is None:                               # CPU / gloo (tests)
@@ -185,7 +189,7 @@ class GradComm:
 
     def reduce(self, flat_g):
         """Issue whatever has not been issued yet (parameters that never reported) and wait for everything."""
-        if self.world > 1:
+        if self.active:
             for idx in range(len(self.buckets)):
                 if not self._issued[idx]:
                     self._issue(idx)

@@ -456,7 +456,7 @@ class _LinearFn(torch.autograd.Function):
         sink_w = getattr(weight, "_yfs_grad_sink", None)
         pending = getattr(weight, "_yfs_factors", None)
         comm = getattr(weight, "_yfs_comm", None)
-        multi = comm is not None and getattr(comm, "world", 1) > 1
+        multi = comm is not None and getattr(comm, "active", getattr(comm, "world", 1) > 1)
         if pending is not None and sink_w is not None:
             # a second backward before the step: the deferred factors become an ordinary gradient first
             if multi:
