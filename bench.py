@@ -26,7 +26,8 @@ import time
 # box).  In the one-GPU rehearsals of the N > 1 path the step stalled with 4 and with 8 queues and
 # ran every time with 16, so multi-rank runs raise a smaller setting to 16 (YFS_KEEP_HW_QUEUES=1 leaves it alone).
 # Read at HIP initialisation, hence set before torch is imported.
-if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("YFS_KEEP_HW_QUEUES") != "1":
+if ((int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("YFS_BENCH_FORCE_DP") == "1")
+        and os.environ.get("YFS_KEEP_HW_QUEUES") != "1"):
     try:
         _q = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
     except ValueError:
