@@ -3,7 +3,7 @@
 is the 2.4 GHz the dense-MFMA peak is quoted at reachable under the conv kernels' load?
     python tools/probes/clock_under_load.py [seconds per load]
 Loads: idle, register-only MFMA loop (yfs_probe_mfma_bf16), feat.18 forward (igemm8_kernel), feat.18 weight gradient
-(wgrad8_kernel), a device-to-device copy (HBM only); the forward also on an all-zero input (same instructions, no toggling
+(wgrad8_kernel), a device-to-device copy (HBM only); the vendor GEMM (torch.mm -> hipBLASLt, 8192^3) on random and on zero operands; the forward also on an all-zero input (same instructions, no toggling
 operands: what the data itself costs in power)."""
 import json, os, subprocess, sys, threading, time
 import torch
@@ -36,14 +36,20 @@ def mfma_ex(shape, toggling):
 
 
 x0 = torch.zeros_like(x)
+ga = (torch.rand(8192, 8192, device=dev) - 0.5).to(torch.bfloat16)
+gb = (torch.rand(8192, 8192, device=dev) - 0.5).to(torch.bfloat16)
+gz = torch.zeros_like(ga)
+gout = torch.empty(8192, 8192, device=dev, dtype=torch.bfloat16)
 MFMA_FLOP = 1024 * 4.0 * 20000 * 16.0 * (2.0 * 16 * 16 * 32)
 L18_FLOP = 2.0 * 64 * 28 * 28 * 1024 * 9 * 512
-FLOPS = {"mfma": MFMA_FLOP, "feat.18": L18_FLOP}
+FLOPS = {"mfma": MFMA_FLOP, "feat.18": L18_FLOP, "hipBLASLt": 2.0 * 8192 ** 3}
 loads = [("idle", None), ("mfma register loop", mfma),
          ("mfma 16x16x32, operands = 1", mfma_ex(0, 0)), ("mfma 16x16x32, random operands", mfma_ex(0, 1)),
          ("mfma 32x32x16, operands = 1", mfma_ex(1, 0)), ("mfma 32x32x16, random operands", mfma_ex(1, 1)), ("feat.18 forward (igemm8)", lambda: co.conv_fwd(x, w16, b, 1)),
          ("feat.18 forward, x = 0", lambda: co.conv_fwd(x0, w16, b, 1)),
-         ("feat.18 wgrad (wgrad8)", lambda: co.conv_wgrad(x, dz, 3, 1)), ("d2d copy 256 MiB", lambda: big2.copy_(big))]
+         ("feat.18 wgrad (wgrad8)", lambda: co.conv_wgrad(x, dz, 3, 1)), ("hipBLASLt 8192^3 bf16, random", lambda: torch.mm(ga, gb, out=gout)),
+         ("hipBLASLt 8192^3 bf16, zeros", lambda: torch.mm(gz, gz, out=gout)),
+         ("d2d copy 256 MiB", lambda: big2.copy_(big))]
 
 
 def sample(out, stop):
