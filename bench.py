@@ -324,13 +324,22 @@ def measured_ceilings(device):
                                                    L.ptr(scratch), L.stream()), "yfs_probe_mfma_bf16_ex")
         ms = _time_ms(run_rnd, 15, warm=15)      # ~0.2 s of load before the timed launches: the clock has settled
         rnd[label] = round(flop.value / (ms * 1e-3) / 1e12, 1)
+    # the vendor's plain GEMM on its friendliest shape, as a yardstick for the conv kernels: torch.mm -> hipBLASLt
+    gemm = {}
+    ga = (torch.rand(8192, 8192, device=device) - 0.5).to(torch.bfloat16)
+    gb = (torch.rand(8192, 8192, device=device) - 0.5).to(torch.bfloat16)
+    gout = torch.empty(8192, 8192, device=device, dtype=torch.bfloat16)
+    for label, (pa, pb) in (("random", (ga, gb)), ("zeros", (torch.zeros_like(ga), torch.zeros_like(gb)))):
+        ms = _time_ms(lambda pa=pa, pb=pb: torch.mm(pa, pb, out=gout), 100, warm=150)
+        gemm[label] = round(2.0 * 8192 ** 3 / (ms * 1e-3) / 1e12, 1)
+    del ga, gb, gout
     return {"hbm_copy_GBps": round(hbm, 1), "mfma_bf16_TFLOPs": round(ones, 1),
-            "mfma_bf16_random_operands_TFLOPs": rnd,
+            "mfma_bf16_random_operands_TFLOPs": rnd, "hipblaslt_gemm_8192_bf16_TFLOPs": gemm,
             "note": "device-to-device copy of 1 GiB (read + write bytes); register-only v_mfma_f32_16x16x32_bf16 loop, "
                     "8 workgroups x 4 waves per CU, at the clock the chip holds under that load; the same loop with "
                     "operands that change from one MFMA to the next (pseudo-random bf16 in +-[0.5, 2)): the matrix pipe "
                     "alone, fed from registers, is power-limited on switching data (DESIGN.md set 1, "
-                    "profiles/r02/clock_under_load.txt)"}
+                    "profiles/r02/clock_under_load.txt); torch.mm (hipBLASLt) on 8192^3 bf16 with random and with zero operands"}
 
 
 def _cpu_model():
