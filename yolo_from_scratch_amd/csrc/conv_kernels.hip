@@ -48,6 +48,21 @@ constexpr int BK = 64;   // reduction depth per LDS tile (128 B rows)
 
 enum { EPI_BIAS_LEAKY = 0, EPI_MASK = 1, EPI_NONE = 2, EPI_POOL = 3 };
 
+// n / d for 0 <= n < 2^31 with a host-prepared multiplier (Granlund-Montgomery round-up form).
+struct FastDiv {
+    unsigned mul, shift, d;
+};
+FastDiv make_fastdiv(unsigned d) {
+    FastDiv f;
+    f.d = d;
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    f.shift = l;
+    f.mul = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) { return (__umulhi(n, f.mul) + n) >> f.shift; }
+
 struct IgemmArgs {
     const bf16_t* x;      // [N,H,W,C]
     const bf16_t* w;      // [NOUT][taps][C]
@@ -69,6 +84,7 @@ struct IgemmArgs {
     // a class only every s-th tap per axis touches a real dz pixel, and those taps form an ordinary stride-1
     // gather over the class's own (OH/s x OW/s) grid, so each class is a dense implicit GEMM with ~1/s^2 of the
     // taps instead of a dilated gather that multiplies zeros 1 - 1/s^2 of the time.
+    FastDiv div_hw, div_w;     // igemm8_kernel: row -> (n, oh, ow) without integer divisions (the pooled grid for EPI_POOL)
     int sub_s;                 // s
     int cls_ph[4], cls_pw[4];  // class parities, heaviest class (most taps) first
     int cls_end[4];            // running end of each class's logical block range (m-tiles of the class x ntiles)
@@ -472,7 +488,7 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
     const int logical = xcd_remap(blockIdx.x, g.mtiles * g.ntiles);
     const int nt = logical % g.ntiles, mt = logical / g.ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
-    const int Mc = g.M, OHc = g.OH, OWc = g.OW;
+    const int Mc = g.M;
 
     // ---- staging coordinates: 4 pixel rows and 4 weight rows per thread (2 per half-tile) -----------------------------
     const int chunk = (lane & 7) ^ (lane >> 3);   // source-side XOR swizzle (see igemm_kernel)
@@ -487,18 +503,19 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
         const int m = m0 + (j >> 1) * 128 + hr;
         if (m < Mc && (j < 2 || hr < FP1 * 32)) {
             int n, oh, ow;
-            if (EPI == EPI_POOL) {   // window-major row order (see igemm_kernel)
-                const int q = m >> 2, sub = m & 3, PW = OWc >> 1, PHW = (OHc >> 1) * PW;
-                n = q / PHW;
-                const int r = q - n * PHW;
-                const int py = r / PW, px = r - py * PW;
+            // (host-prepared multipliers: four rows x two divisions per thread were ~280 instructions of every tile's prologue)
+            if (EPI == EPI_POOL) {   // window-major row order (see igemm_kernel); div_hw / div_w divide by the pooled grid
+                const int q = m >> 2, sub = m & 3;
+                n = (int)fdiv((unsigned)q, g.div_hw);
+                const int r = q - n * (int)g.div_hw.d;
+                const int py = (int)fdiv((unsigned)r, g.div_w), px = r - py * (int)g.div_w.d;
                 oh = 2 * py + (sub >> 1);
                 ow = 2 * px + (sub & 1);
             } else {
-                n = m / (OHc * OWc);
-                const int rem = m - n * (OHc * OWc);
-                oh = rem / OWc;
-                ow = rem - oh * OWc;
+                n = (int)fdiv((unsigned)m, g.div_hw);
+                const int rem = m - n * (int)g.div_hw.d;
+                oh = (int)fdiv((unsigned)rem, g.div_w);
+                ow = rem - oh * (int)g.div_w.d;
             }
             const int bh = oh * g.s_mul - g.pad, bw = ow * g.s_mul - g.pad;
             st[4 + j] = ((unsigned)bh << 16) | ((unsigned)bw & 0xFFFFu);
@@ -770,6 +787,8 @@ template <int EPI, int FP1>
 int launch_igemm8(IgemmArgs& g, hipStream_t s, const char* name) {
     g.mtiles = (int)yfs_cdiv(g.M, 128 + FP1 * 32);
     g.ntiles = g.NOUT / 256;
+    g.div_hw = make_fastdiv(EPI == EPI_POOL ? (unsigned)((g.OH / 2) * (g.OW / 2)) : (unsigned)(g.OH * g.OW));
+    g.div_w = make_fastdiv(EPI == EPI_POOL ? (unsigned)(g.OW / 2) : (unsigned)g.OW);
     auto kern = igemm8_kernel<EPI, FP1>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, B8_LDS_IG);
     YFS_REQUIRE(e == hipSuccess, YFS_ERR_LAUNCH, "%s: cannot reserve %d bytes of LDS", name, B8_LDS_IG);
@@ -933,21 +952,6 @@ YFS_API int yfs_conv2d_dgrad_bf16(const void* dz, const void* wt, const void* x_
 
 // =============================== wgrad ==========================================================
 namespace {
-
-// n / d for 0 <= n < 2^31 with a host-prepared multiplier (Granlund-Montgomery round-up form).
-struct FastDiv {
-    unsigned mul, shift, d;
-};
-FastDiv make_fastdiv(unsigned d) {
-    FastDiv f;
-    f.d = d;
-    unsigned l = 0;
-    while ((1ull << l) < d) ++l;
-    f.shift = l;
-    f.mul = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
-    return f;
-}
-__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) { return (__umulhi(n, f.mul) + n) >> f.shift; }
 
 struct WgradArgs {
     const bf16_t* dz;   // [M][Cout]   (POOLZ: the POOLED gradient [M/4][Cout])
