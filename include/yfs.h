@@ -45,7 +45,8 @@ int yfs_last_error(char *buf, size_t n);
  * values come from the environment variables of the same name (YFS_IGEMM_TILE, YFS_WGRAD_TILE, YFS_WGRAD_SPLITS,
  * YFS_NMS_FUSED, YFS_STEM_KERNEL), read once at the first use of any knob.  Changing a knob while another thread launches kernels
  * affects that thread's tile choice, never its results beyond fp32 summation order.
- *   YFS_KNOB_IGEMM_TILE    forward/dgrad workgroup tile: 128 | 64128 | 224 | 2562 | 256 | 8 (256x256, 8-phase) | 87 (224x256, 8-phase)
+ *   YFS_KNOB_IGEMM_TILE    forward/dgrad workgroup tile: 128 | 64128 | 224 | 2562 | 256 | 8 (256x256, 8-phase) | 87 (224x256, 8-phase) |
+ *                          192 (8-phase, 192-channel tile: masked dgrad with 192 output channels only)
  *   YFS_KNOB_WGRAD_TILE    weight-gradient tile: 64 | 12864 | 128 (wgrad_kernel, its own tile choice) | 8 (wgrad8_kernel: 256-wide tiles)
  *   YFS_KNOB_WGRAD_SPLITS  split-K factor of the weight gradient (> 0 forces it)
  *   YFS_KNOB_NMS_FUSED     1: yfs_decode_nms_f32 decodes inside the NMS kernel (one launch)

@@ -301,6 +301,28 @@ def test_big_igemm_tiles_are_bit_identical_to_the_default(tile):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("n,cout,k,hw", [(2, 256, 3, 20), (3, 320, 3, 15), (1, 128, 1, 33), (5, 64, 3, 28)])
+def test_dgrad_192_channel_8phase_tile_is_bit_identical_to_the_small_kernel(n, cout, k, hw):
+    """feat.2's dgrad writes 192 channels: igemm8_kernel<EPI_MASK, FP1, FW1 = 1> (192-channel tile, second weight half-tile
+    64 rows) forced through the tuning knob against igemm_kernel<128,192> on ragged pixel counts, odd and even K-step
+    counts, 256- and 224-row tiles; masked dgrad only (the one epilogue this tile is built for)."""
+    from yolo_from_scratch_amd import _lib as L
+    g = torch.Generator().manual_seed(n + cout + hw)
+    dz = co.nhwc(torch.randn(n, cout, hw, hw, generator=g).to(DEV), torch.bfloat16)
+    act = co.nhwc(torch.randn(n, 192, hw, hw, generator=g).to(DEV), torch.bfloat16)
+    w = co.nhwc(((torch.rand(cout, 192, k, k, generator=g) * 2 - 1) / (cout * k * k) ** 0.5).to(DEV))
+    wt16 = co.weight_prep(w)[1]
+    L.set_knob("igemm_tile", 128)
+    try:
+        ref = co.conv_dgrad(dz, wt16, (hw, hw), 1, x_act=act)
+        L.set_knob("igemm_tile", 192)
+        got = co.conv_dgrad(dz, wt16, (hw, hw), 1, x_act=act)
+    finally:
+        L.set_knob("igemm_tile", 0)
+    assert got.shape == ref.shape == (n, 192, hw, hw)
+    assert torch.equal(got, ref)
+
+
 @pytest.mark.parametrize("n,cin,cout,k,s,hw", [(2, 256, 256, 3, 1, 9), (3, 192, 256, 3, 1, 12), (1, 512, 512, 1, 1, 14),
                                                (2, 256, 512, 3, 2, 14), (5, 192, 256, 3, 1, 20), (2, 512, 256, 3, 1, 6)])
 def test_wgrad_8phase_kernel_matches_default(n, cin, cout, k, s, hw):

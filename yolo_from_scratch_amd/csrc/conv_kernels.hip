@@ -476,9 +476,11 @@ __device__ long long yfs_ig8_dbg[8];
 #else
 #define IG8_T(k) do { } while (0)
 #endif
-template <int EPI, int FP1>
+// FW1 = channel fragments per wave in the SECOND weight half-tile: 2 -> 256-channel tile, 1 -> 192-channel tile (W1 holds
+// 64 rows, its MFMA blocks are half as long): feat.2's dgrad writes 192 channels.
+template <int EPI, int FP1, int FW1 = 2>
 __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
-    constexpr int BM = 128 + FP1 * 32, BN = 256, NT = 512;
+    constexpr int BM = 128 + FP1 * 32, BN = 128 + FW1 * 64, NT = 512;
     IG8_T(0);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -586,20 +588,21 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
             for (int ks = 0; ks < 2; ++ks)
                 pf[b][ks] = *reinterpret_cast<const bf16x8*>(hb + swz(wm * (NF * 16) + b * 16 + frow, ks * 4 + fk));
     };
-    auto read_W = [&](const unsigned char* hb, bf16x8 (&wf)[2][2]) {
+    auto read_W = [&](const unsigned char* hb, bf16x8 (&wf)[2][2], auto na_tag) {   // na_tag: channel fragments per wave (2 or FW1)
+        constexpr int NA = decltype(na_tag)::value;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < NA; ++a)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                wf[a][ks] = *reinterpret_cast<const bf16x8*>(hb + swz(wn * 32 + a * 16 + frow, ks * 4 + fk));
+                wf[a][ks] = *reinterpret_cast<const bf16x8*>(hb + swz(wn * (NA * 16) + a * 16 + frow, ks * 4 + fk));
     };
-    auto mfma16 = [&](f32x4 (&c)[2][4], const bf16x8 (&wf)[2][2], auto nf_tag) {
-        constexpr int NF = decltype(nf_tag)::value;
+    auto mfma16 = [&](f32x4 (&c)[2][4], const bf16x8 (&wf)[2][2], auto nf_tag, auto na_tag) {
+        constexpr int NF = decltype(nf_tag)::value, NA = decltype(na_tag)::value;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < NA; ++a)
 #pragma unroll
                 for (int b = 0; b < NF; ++b) c[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a][ks], pf[b][ks], c[a][b], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
@@ -627,18 +630,20 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
 
     const std::integral_constant<int, 4> F4;
     const std::integral_constant<int, FP1> F1;
+    const std::integral_constant<int, 2> A2;
+    const std::integral_constant<int, FW1> A1;
     auto tile = [&](int t, auto buf_tag) {
         constexpr int BUF = decltype(buf_tag)::value;
         const unsigned char* tb = smem + BUF * B8_BUF;
         // phase A
-        read_W(tb + 2 * B8_HALF, w0f);
+        read_W(tb + 2 * B8_HALF, w0f, A2);
         read_P(tb, F4);
-        read_W(tb + 3 * B8_HALF, w1f);
+        read_W(tb + 3 * B8_HALF, w1f, A1);
         if (t + 1 < nit) stage_P(1, BUF ^ 1);
         lgkm0();
         bar();
-        mfma16(acc[0][0], w0f, F4);
-        mfma16(acc[0][1], w1f, F4);
+        mfma16(acc[0][0], w0f, F4, A2);
+        mfma16(acc[0][1], w1f, F4, A1);
         bar();
         // phase B
         read_P(tb + B8_HALF, F1);
@@ -653,8 +658,8 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
         }
         lgkm0();
         bar();
-        mfma16(acc[1][1], w1f, F1);
-        mfma16(acc[1][0], w0f, F1);
+        mfma16(acc[1][1], w1f, F1, A1);
+        mfma16(acc[1][0], w0f, F1, A2);
         bar();
     };
     int t = 0;
@@ -669,8 +674,9 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
     // ---- epilogue: the fp32 tile through LDS in 64-row slabs, then coalesced 16 B stores (as igemm_kernel) ----
     // acc[ph][wh][a][b][r] = out[pixel ph*128 + wm*NF*16 + b*16 + (lane&15)][chan wh*128 + wn*32 + a*16 + (lane>>4)*4 + r]
     // with NF = 4 fragments per wave in the first pixel half and FP1 in the second; slab = one wave row of one half
-    constexpr int TPR = BN / 8, RPP = NT / TPR;
+    constexpr int TPR = BN / 8, RPP = NT / TPR;          // (192 channels: 24 threads per row, 21 rows per sweep, 8 threads idle)
     const int ec = (tid % TPR) * 8, er = tid / TPR;
+    const bool sweeper = tid < RPP * TPR;
     float bv[8], sv[8];
     if (EPI == EPI_BIAS_LEAKY) {
 #pragma unroll
@@ -697,8 +703,8 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    if (b >= NF) continue;
-                    const int ch = wh * 128 + wn * 32 + a * 16 + fk * 4;
+                    if (b >= NF || (wh == 1 && a >= FW1)) continue;
+                    const int ch = wh * 128 + wn * (wh == 1 ? FW1 * 16 : 32) + a * 16 + fk * 4;
                     *reinterpret_cast<f32x4*>(myslab + (b * 16 + frow) * B8_EPI_STRIDE + ch * 4) = acc[ph][wh][a][b];
                 }
         __syncthreads();
@@ -741,7 +747,7 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
                 const int rr = er + p * RPP;                          // row of the two stacked slabs
-                if (rr >= 2 * PR) continue;
+                if (rr >= 2 * PR || !sweeper) continue;
                 const int sl = rr >= PR ? 1 : 0, row = rr - sl * PR;
                 const int m = m0 + rbase + rr;
                 if (m >= Mc) continue;
@@ -783,13 +789,13 @@ extern "C" __attribute__((visibility("default"))) int yfs_debug_ig8_times(long l
 }
 namespace {
 #endif
-template <int EPI, int FP1>
+template <int EPI, int FP1, int FW1 = 2>
 int launch_igemm8(IgemmArgs& g, hipStream_t s, const char* name) {
     g.mtiles = (int)yfs_cdiv(g.M, 128 + FP1 * 32);
-    g.ntiles = g.NOUT / 256;
+    g.ntiles = g.NOUT / (128 + FW1 * 64);
     g.div_hw = make_fastdiv(EPI == EPI_POOL ? (unsigned)((g.OH / 2) * (g.OW / 2)) : (unsigned)(g.OH * g.OW));
     g.div_w = make_fastdiv(EPI == EPI_POOL ? (unsigned)(g.OW / 2) : (unsigned)g.OW);
-    auto kern = igemm8_kernel<EPI, FP1>;
+    auto kern = igemm8_kernel<EPI, FP1, FW1>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, B8_LDS_IG);
     YFS_REQUIRE(e == hipSuccess, YFS_ERR_LAUNCH, "%s: cannot reserve %d bytes of LDS", name, B8_LDS_IG);
     kern<<<dim3((unsigned)(g.mtiles * g.ntiles)), dim3(512), B8_LDS_IG, s>>>(g);
@@ -820,6 +826,13 @@ int launch_igemm8(IgemmArgs& g, hipStream_t s, const char* name) {
 template <int EPI, bool SUB>
 int dispatch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
     const int force = yfs_knob(YFS_KNOB_IGEMM_TILE);
+    if constexpr (EPI == EPI_MASK && !SUB) {
+        // feat.2's dgrad (192 output channels, K = 2304): the 8-phase kernel with a 192-channel tile (knob 192 forces
+        // it, knob 128 the small kernel)
+        const bool fits = g.NOUT == 192 && g.H < 16000 && g.W < 16000 && g.OH * g.s_mul < 16000 && g.OW * g.s_mul < 16000;
+        if (fits && (force == 192 || (force == 0 && g.KH * g.KW * g.C >= 1152 && yfs_cdiv(g.M, 256) >= 200)))
+            return g.M % 256 == 0 || g.M % 224 != 0 ? launch_igemm8<EPI, 4, 1>(g, s, name) : launch_igemm8<EPI, 3, 1>(g, s, name);
+    }
     if (g.NOUT % 192 == 0 && g.NOUT % 128 != 0 && force != 64) return launch_igemm<128, 192, 2, 2, 2, EPI, SUB>(g, s, name);
     if (g.NOUT % 128 != 0) return launch_igemm<128, 64, 2, 2, 2, EPI, SUB>(g, s, name);
     // (igemm8_kernel packs a row's source coordinates into 16 bits each)
