@@ -57,7 +57,7 @@ PMC_TRAFFIC_BYTES = {"nms": 137.0e6, "loss": 1129.5e6, "assign": 264.2e6}
 # MFMA utilisation of the conv kernels from the PMC counters (SQ_VALU_MFMA_BUSY_CYCLES over the active cycles of all SIMDs;
 # rocprofv3 --pmc passes over tools/conv_bench.py, profiles/r02/conv_pmc_summary.txt).  Committed measurements, as above.
 PMC_MFMA_BUSY = {"igemm8_kernel (3x3 forward / dgrad)": [0.52, 0.60], "wgrad8_kernel (3x3 weight gradient)": [0.49, 0.54],
-                 "stem_pool_kernel": 0.50, "igemm_kernel<128,192> (feat.2 dgrad)": 0.47,
+                 "stem_pool_kernel": 0.49, "igemm8_kernel<mask, 256 rows, 192 channels> (feat.2 dgrad)": 0.46,
                  "source": "profiles/r02/conv_pmc_summary.txt"}
 
 

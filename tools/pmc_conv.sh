@@ -3,7 +3,7 @@
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/r2/pmc3
+OUT=$R/gpurun_out/r2/${PMC_TAG:-pmc5}
 mkdir -p $OUT
 CMD="python3 $R/tools/conv_bench.py --iters 3 --ops fwdpool,fwd,dgrad,wgrad --layers 0,2,7,18,24"
 i=0
