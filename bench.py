@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """bench.py — BASELINE.json metric on BASELINE.json's config.
 
-    python bench.py --gpus N --steps K --warmup W            (N = 1)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+    python bench.py --gpus N --steps K --warmup W            (N = 1, or N > 1: starts its own N rank processes)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1 under a launcher)
 
 A "step" is one YOLOv1-448 train step (S=7, B=2, C=20, per-GPU batch 64, bf16 conv on MFMA): zero_grad,
 forward (24 Conv2D blocks + 4 pools + fc head), fused composite loss, backward, RCCL gradient exchange
@@ -35,12 +35,91 @@ if ((int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("YFS_BENCH_FOR
     if _q < 16:
         os.environ["GPU_MAX_HW_QUEUES"] = "16"
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+# ---- `python bench.py --gpus N` without a launcher: this process becomes a parent that never touches the GPU ----------
+def rank_environments(n, port, base=None):
+    """Environment of each of the n rank processes (what torch.distributed.run would export), one rank per GPU."""
+    envs = []
+    for r in range(n):
+        e = dict(os.environ if base is None else base)
+        e.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                  "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+        envs.append(e)
+    return envs
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv, child=None, watchdog_s=None):
+    """Start n fresh rank processes of this script (never an exec of this one, never a fork after HIP initialisation:
+    the parent imports neither torch nor the library), relay rank 0's stdout, forward every rank's stderr, and return a
+    non-zero code if any rank fails or the watchdog fires (the remaining ranks are then killed by PID)."""
+    import subprocess
+    import threading
+    child = child or [sys.executable, "-u", os.path.abspath(__file__)]
+    watchdog_s = watchdog_s or int(os.environ.get("YFS_BENCH_WATCHDOG_S", "600")) + 60
+    port = int(os.environ.get("MASTER_PORT", "0")) or _free_port()
+    procs = []
+    for r, env in enumerate(rank_environments(n, port)):
+        procs.append(subprocess.Popen(child + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      stderr=None, text=True))
+    lines = []
+    reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout), daemon=True)
+    reader.start()
+    deadline = time.monotonic() + watchdog_s
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is not None:
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print(f"bench.py: rank {r} exited with {code}", file=sys.stderr, flush=True)
+        if pending and (rc != 0 or time.monotonic() > deadline):
+            if rc == 0:
+                rc = 124
+                print(f"bench.py: ranks {sorted(pending)} still running after {watchdog_s} s; killing them", file=sys.stderr,
+                      flush=True)
+            for r in pending:
+                procs[r].kill()
+            for r in pending:
+                procs[r].wait()
+            break
+        time.sleep(0.2)
+    reader.join(timeout=5)
+    sys.stdout.write("".join(lines))
+    sys.stdout.flush()
+    return rc
+
+
+def _wants_parent(argv):
+    """--gpus N > 1 given to a process no launcher has prepared (no WORLD_SIZE in the environment)."""
+    n = 1
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    return n if (n > 1 and "WORLD_SIZE" not in os.environ) else 0
+
+
+if __name__ == "__main__" and _wants_parent(sys.argv[1:]):
+    sys.exit(launch_ranks(_wants_parent(sys.argv[1:]), sys.argv[1:]))
+
+import numpy as np          # noqa: E402
+import torch                # noqa: E402
+import torch.distributed as dist   # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0         # HBM3E spec, same table
@@ -382,8 +461,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
+        # (without WORLD_SIZE in the environment `--gpus N` starts its own ranks: launch_ranks above)
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world} set by the launcher")
     # Rehearsal of the N > 1 code path on a one-GPU box (YFS_BENCH_ONE_GPU=1): every rank on device 0, gloo instead of
     # RCCL (two RCCL ranks cannot share a device).  Never used by the driver; its numbers mean nothing.
     one_gpu = os.environ.get("YFS_BENCH_ONE_GPU") == "1"

@@ -55,6 +55,11 @@ typedef enum { YFS_KNOB_IGEMM_TILE = 0, YFS_KNOB_WGRAD_TILE = 1, YFS_KNOB_WGRAD_
                YFS_KNOB_STEM_KERNEL = 4, YFS_KNOB_COUNT = 5 } yfs_knob_id;
 int yfs_set_knob(int knob, int value);
 int yfs_get_knob(int knob);
+/* Dispatch query (no reference counterpart: the reference has one conv code path, torch's): the kernel variant the
+ * calling thread's last yfs_conv2d_* / yfs_linear_wgrad_sgd_bf16 call launched, e.g. "igemm8_kernel<224,256,epi0>" or
+ * "wgrad8_kernel<256,256,splits7>".  Thread-local like yfs_last_error; the parity tests use it to assert that the
+ * auto-dispatched kernel is the one they mean to check.  Copies at most n bytes (NUL-terminated); returns the length. */
+int yfs_last_kernel(char *buf, size_t n);
 
 /* ---- kernel set 3: box math, decode, NMS ---------------------------------------------------- */
 

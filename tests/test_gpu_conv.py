@@ -379,3 +379,45 @@ def test_conv_folded_batchnorm_leaky_epilogue(n, cin, cout, k, s, hw):
     y = co.conv_fwd_affine(xd, w16, scale.to(DEV), shift.to(DEV), s)
     _close(y, ref, "conv + folded BN + leaky")
     assert torch.equal(co.conv_fwd_affine(xd, w16, None, b.to(DEV), s), co.conv_fwd(xd, w16, b.to(DEV), s))
+
+
+# ---- the auto-dispatched 8-phase kernels at BASELINE config-2 layer shapes, straight against torch-CPU fp32 --------------
+# (reference call sites: Conv2D blocks yolo_toy_regressor_torch.py:206-211, feat.18 = Conv2D(512, 1024, 3) :241,
+#  feat.2 = Conv2D(192, 256, 3) :223; the batch is cut to what the CPU finishes in seconds, the per-image geometry and
+#  the channel counts — which decide the kernel — are the real ones)
+REAL_LAYERS = [  # name, n, cin, cout, k, hw, expected forward kernel, expected masked-dgrad kernel, expected wgrad kernel
+    ("feat.18", 8, 512, 1024, 3, 28, "igemm8_kernel<224,256,epi0>", "igemm8_kernel<224,256,epi1>", "wgrad8_kernel<256,256"),
+    ("feat.2", 4, 192, 256, 3, 112, "igemm8_kernel<224,256,epi0>", "igemm8_kernel<224,192,epi1>", "wgrad8_kernel<192,256"),
+]
+
+
+@pytest.mark.parametrize("name,n,cin,cout,k,hw,k_fwd,k_dgrad,k_wgrad", REAL_LAYERS)
+def test_8phase_kernels_at_real_layer_shapes_vs_torch_cpu(name, n, cin, cout, k, hw, k_fwd, k_dgrad, k_wgrad):
+    """Forward, masked dgrad and wgrad + bias gradient of feat.18 / feat.2 on whatever the library dispatches by itself
+    (no knob), compared with torch-CPU fp32 on the same bf16-rounded operands at north_star's 1e-2; the dispatch query
+    proves that the 8-phase kernels are what ran."""
+    from yolo_from_scratch_amd import _lib as L
+    assert L.get_knob("igemm_tile") == 0 and L.get_knob("wgrad_tile") == 0 and L.get_knob("wgrad_splits") == 0
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    x, w, b = _case(n, cin, cout, k, hw, seed=cin + hw)
+    x = x - 0.35                                       # the block's input is a LeakyReLU output: both signs
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    z_ref = F.conv2d(xr, wr, br, stride=1, padding=k // 2)
+    y_ref = F.leaky_relu(z_ref, 0.1)
+    dz = _bf(torch.randn(z_ref.shape, generator=torch.Generator().manual_seed(7)))
+    xg, wg, bg = torch.autograd.grad(z_ref, (xr, wr, br), dz)
+    xg = xg * torch.where(x > 0, 1.0, 0.1)             # the dgrad epilogue applies the previous block's LeakyReLU'
+
+    xd = co.nhwc(x.to(DEV), torch.bfloat16)
+    w16, wt16 = co.weight_prep(co.nhwc(w.to(DEV)))
+    y = co.conv_fwd(xd, w16, b.to(DEV), 1)
+    assert L.last_kernel() == k_fwd, L.last_kernel()
+    _close(y, y_ref.detach(), f"{name} forward")
+    dzd = co.nhwc(dz.to(DEV), torch.bfloat16)
+    dx = co.conv_dgrad(dzd, wt16, (hw, hw), 1, x_act=xd)
+    assert L.last_kernel() == k_dgrad, L.last_kernel()
+    _close(dx, xg, f"{name} masked dgrad")
+    dw, db = co.conv_wgrad(xd, dzd, k, 1)
+    assert L.last_kernel().startswith(k_wgrad), L.last_kernel()
+    _close(dw, wg, f"{name} wgrad")
+    _close(db, bg, f"{name} bias grad")

@@ -78,8 +78,8 @@ def main():
         flops = 2.0 * a.batch * oh * ow * cout * cin * k * k
         line = f"L{li:<2d} {cin:4d}->{cout:4d} k{k} s{s} {hw:3d}^2  GF={flops / 1e9:7.1f}"
         for op in a.ops.split(","):
-            if op == "wgradpool":
-                continue          # stem only
+            if op == "wgradpool" or (op == "fwdpool" and oh % 2):
+                continue          # stem only / odd output: no fused pool
             fn = {"fwd": lambda: co.conv_fwd(x, w16, b, s), "fwdpool": lambda: co.conv_fwd_pool(x, w16, b, s),
                   "dgrad": lambda: co.conv_dgrad(dz, wt16, (hw, hw), s, x_act=x),
                   "wgrad": lambda: co.conv_wgrad(x, dz, k, s)}[op]

@@ -50,6 +50,13 @@ def last_error():
     return buf.value.decode("utf-8", "replace")
 
 
+def last_kernel():
+    """Kernel variant the calling thread's last conv entry point launched (include/yfs.h: yfs_last_kernel)."""
+    buf = ctypes.create_string_buffer(128)
+    lib().yfs_last_kernel(buf, ctypes.c_size_t(128))
+    return buf.value.decode("utf-8", "replace")
+
+
 def check(status, what):
     if status != 0:
         raise YfsError(f"{what} failed with status {status}: {last_error()}")

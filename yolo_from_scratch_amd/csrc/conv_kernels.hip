@@ -441,6 +441,7 @@ int launch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
     }
     kern<<<dim3((unsigned)nblk), dim3(64 * WM * WN), lds, s>>>(g);
     YFS_CHECK_LAUNCH(name);
+    yfs_note_kernel("igemm_kernel<%d,%d,epi%d%s>", BM, BN, EPI, SUB ? ",sub" : "");
     return YFS_OK;
 }
 
@@ -800,6 +801,7 @@ int launch_igemm8(IgemmArgs& g, hipStream_t s, const char* name) {
     YFS_REQUIRE(e == hipSuccess, YFS_ERR_LAUNCH, "%s: cannot reserve %d bytes of LDS", name, B8_LDS_IG);
     kern<<<dim3((unsigned)(g.mtiles * g.ntiles)), dim3(512), B8_LDS_IG, s>>>(g);
     YFS_CHECK_LAUNCH(name);
+    yfs_note_kernel("igemm8_kernel<%d,%d,epi%d>", 128 + FP1 * 32, 128 + FW1 * 64, EPI);
     return YFS_OK;
 }
 
@@ -1817,6 +1819,7 @@ int launch_wgrad8(WgradArgs& g, const WgradPlan& p, hipStream_t s) {
     const int nblk = p.cotiles * p.citiles * g.KH * g.KW * p.splits;
     kern<<<dim3((unsigned)nblk), dim3(512), B8_LDS, s>>>(g);
     YFS_CHECK_LAUNCH("wgrad8_kernel");
+    yfs_note_kernel("wgrad8_kernel<%d,256,splits%d>", FX * 64, p.splits);
     return YFS_OK;
 }
 
@@ -1831,6 +1834,7 @@ int launch_wgrad(WgradArgs& g, const WgradPlan& p, hipStream_t s) {
     const int nblk = p.cotiles * p.citiles * g.KH * g.KW * p.splits;
     kern<<<dim3((unsigned)nblk), dim3(kThreads), lds, s>>>(g);
     YFS_CHECK_LAUNCH("wgrad_kernel");
+    yfs_note_kernel("wgrad_kernel<%d,%d%s%s,splits%d>", BX, BZ, POOLZ ? ",poolz" : "", SGD ? ",sgd" : "", p.splits);
     return YFS_OK;
 }
 

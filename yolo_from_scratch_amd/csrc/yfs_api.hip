@@ -1,6 +1,7 @@
 // libyfs.so: version, thread-local error reporting, tuning knobs.
 #include "yfs_common.h"
 #include <atomic>
+#include <mutex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -15,7 +16,25 @@ void yfs_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-YFS_API int yfs_version(void) { return 200; }
+YFS_API int yfs_version(void) { return 300; }
+
+// ---- dispatch query: which conv kernel variant the calling thread's last conv entry point launched ------------------
+static thread_local char g_kernel[96] = {0};
+void yfs_note_kernel(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+    va_end(ap);
+}
+YFS_API int yfs_last_kernel(char* buf, size_t n) {
+    size_t len = strlen(g_kernel);
+    if (buf && n) {
+        size_t c = len < n - 1 ? len : n - 1;
+        memcpy(buf, g_kernel, c);
+        buf[c] = 0;
+    }
+    return (int)len;
+}
 
 YFS_API int yfs_last_error(char* buf, size_t n) {
     size_t len = strlen(g_err);
@@ -30,15 +49,15 @@ YFS_API int yfs_last_error(char* buf, size_t n) {
 // ---- tuning knobs (include/yfs.h: measurement aids; the library's only process-wide mutable state) ------------------
 namespace {
 std::atomic<int> g_knob[YFS_KNOB_COUNT];
-std::atomic<int> g_knob_init{0};
+std::once_flag g_knob_once;
 const char* const kKnobEnv[YFS_KNOB_COUNT] = {"YFS_IGEMM_TILE", "YFS_WGRAD_TILE", "YFS_WGRAD_SPLITS", "YFS_NMS_FUSED", "YFS_STEM_KERNEL"};
-void knob_init() {   // the environment gives the initial values, read once (racing first calls write the same values)
-    if (g_knob_init.load(std::memory_order_acquire)) return;
-    for (int k = 0; k < YFS_KNOB_COUNT; ++k) {
-        const char* e = getenv(kKnobEnv[k]);
-        g_knob[k].store(e ? atoi(e) : 0, std::memory_order_relaxed);
-    }
-    g_knob_init.store(1, std::memory_order_release);
+void knob_init() {   // the environment gives the initial values, read exactly once: a later yfs_set_knob always wins
+    std::call_once(g_knob_once, [] {
+        for (int k = 0; k < YFS_KNOB_COUNT; ++k) {
+            const char* e = getenv(kKnobEnv[k]);
+            g_knob[k].store(e ? atoi(e) : 0, std::memory_order_relaxed);
+        }
+    });
 }
 }  // namespace
 

@@ -9,6 +9,8 @@
 
 // thread-local error message (yfs_api.hip)
 void yfs_set_error(const char* fmt, ...);
+// records the kernel variant an entry point chose (thread-local; read back with yfs_last_kernel)
+void yfs_note_kernel(const char* fmt, ...);
 // current value of a tuning knob (yfs_knob_id in include/yfs.h; 0 = automatic choice)
 int yfs_knob(int knob);
 
