@@ -46,7 +46,8 @@ int yfs_last_error(char *buf, size_t n);
  * YFS_NMS_FUSED, YFS_STEM_KERNEL), read once at the first use of any knob.  Changing a knob while another thread launches kernels
  * affects that thread's tile choice, never its results beyond fp32 summation order.
  *   YFS_KNOB_IGEMM_TILE    forward/dgrad workgroup tile: 128 | 64128 | 224 | 2562 | 256 | 8 (256x256, 8-phase) | 87 (224x256, 8-phase) |
- *                          192 (8-phase, 192-channel tile: masked dgrad with 192 output channels only)
+ *                          192 (8-phase, 192-channel tile: masked dgrad with 192 output channels only) |
+ *                          84 (8-phase with split-K whatever the shape; needs the _ws entry points)
  *   YFS_KNOB_WGRAD_TILE    weight-gradient tile: 64 | 12864 | 128 (wgrad_kernel, its own tile choice) | 8 (wgrad8_kernel: 256-wide tiles)
  *   YFS_KNOB_WGRAD_SPLITS  split-K factor of the weight gradient (> 0 forces it)
  *   YFS_KNOB_NMS_FUSED     1: yfs_decode_nms_f32 decodes inside the NMS kernel (one launch)
@@ -160,6 +161,21 @@ int yfs_conv2d_fwd_affine_bf16(const void *x, const void *w, const float *scale,
  * activation derivative is applied in the epilogue. */
 int yfs_conv2d_dgrad_bf16(const void *dz, const void *wt, const void *x_act, void *dx, int64_t N, int H, int W,
                           int Cin, int Cout, int K, int stride, float slope, void *stream);
+/* The same two operations with a caller-owned workspace (same reference call sites: Conv2D blocks :206-211 and their
+ * autograd).  A GEMM with few pixels and a long reduction (feat.25-27, :250-254: 64 x 7 x 7 pixels, K = 9216) cannot fill
+ * 256 CUs with 256-wide tiles; given yfs_conv2d_{fwd,dgrad}_workspace_bytes() bytes of scratch the library splits the
+ * reduction over workgroups (fp32 partial tiles in the workspace, summed in split order: deterministic) and applies the
+ * epilogue in the reduction.  The byte count is 0 for every shape that does not split; workspace == NULL always runs
+ * the unsplit kernels (results differ from the split form only in fp32 summation order before the one bf16 rounding).
+ * yfs_conv2d_fwd_ws_bf16 takes the folded-BN form's arguments (scale == NULL: bias-only block). */
+size_t yfs_conv2d_fwd_workspace_bytes(int64_t N, int H, int W, int Cin, int Cout, int K, int stride);
+size_t yfs_conv2d_dgrad_workspace_bytes(int64_t N, int H, int W, int Cin, int Cout, int K, int stride);
+int yfs_conv2d_fwd_ws_bf16(const void *x, const void *w, const float *scale, const float *shift, void *y, int64_t N,
+                           int H, int W, int Cin, int Cout, int K, int stride, float slope, void *workspace,
+                           size_t workspace_bytes, void *stream);
+int yfs_conv2d_dgrad_ws_bf16(const void *dz, const void *wt, const void *x_act, void *dx, int64_t N, int H, int W,
+                             int Cin, int Cout, int K, int stride, float slope, void *workspace, size_t workspace_bytes,
+                             void *stream);
 /* dw [Cout,K,K,Cin] fp32 (+)= sum_pixels dz (x) x ; db [Cout] fp32 (+)= sum_pixels dz.
  * accumulate != 0 adds into dw/db (gradient accumulation), else overwrites. */
 size_t yfs_conv2d_wgrad_workspace_bytes(int64_t N, int H, int W, int Cin, int Cout, int K, int stride);

@@ -386,8 +386,11 @@ def test_conv_folded_batchnorm_leaky_epilogue(n, cin, cout, k, s, hw):
 #  feat.2 = Conv2D(192, 256, 3) :223; the batch is cut to what the CPU finishes in seconds, the per-image geometry and
 #  the channel counts — which decide the kernel — are the real ones)
 REAL_LAYERS = [  # name, n, cin, cout, k, hw, expected forward kernel, expected masked-dgrad kernel, expected wgrad kernel
-    ("feat.18", 8, 512, 1024, 3, 28, "igemm8_kernel<224,256,epi0>", "igemm8_kernel<224,256,epi1>", "wgrad8_kernel<256,256"),
-    ("feat.2", 4, 192, 256, 3, 112, "igemm8_kernel<224,256,epi0>", "igemm8_kernel<224,192,epi1>", "wgrad8_kernel<192,256"),
+    ("feat.18", 32, 512, 1024, 3, 28, "igemm8_kernel<224,256,epi0>", "igemm8_kernel<224,256,epi1>", "wgrad8_kernel<256,256"),
+    ("feat.2", 8, 192, 256, 3, 112, "igemm8_kernel<224,256,epi0>", "igemm8_kernel<256,192,epi1>", "wgrad8_kernel<192,256"),
+    # feat.26 / feat.27 = Conv2D(1024, 1024, 3) at 7x7 (:253-254), full batch: 3136 pixels, K = 9216 -> split-K form
+    ("feat.26", 64, 1024, 1024, 3, 7, "igemm8_kernel<224,256,epi4,ksplit4>+splitk_epilogue<epi0>",
+     "igemm8_kernel<224,256,epi4,ksplit4>+splitk_epilogue<epi1>", "wgrad8_kernel<256,256"),
 ]
 
 
@@ -421,3 +424,48 @@ def test_8phase_kernels_at_real_layer_shapes_vs_torch_cpu(name, n, cin, cout, k,
     assert L.last_kernel().startswith(k_wgrad), L.last_kernel()
     _close(dw, wg, f"{name} wgrad")
     _close(db, bg, f"{name} bias grad")
+
+
+@pytest.mark.parametrize("n,cin,cout,k,s,hw", [(3, 64, 256, 3, 1, 15), (2, 128, 512, 1, 1, 14), (1, 192, 256, 3, 1, 30),
+                                               (2, 64, 256, 3, 2, 14), (4, 320, 256, 3, 1, 7)])
+def test_split_k_form_of_the_8phase_kernel_matches_the_unsplit_kernels(n, cin, cout, k, s, hw):
+    """igemm8_kernel<EPI_PARTIAL> + splitk_epilogue_kernel forced through the tuning knob (84) on ragged shapes: pixel
+    counts that are no multiple of the tile, K-step counts of 2 ... 45 that the split does not divide, stride 2, folded
+    BN scale, masked and plain dgrad.  The K-steps are the same; only the fp32 summation order changes before the one
+    rounding to bf16, so the outputs may differ by one bf16 ulp where a sum sits on a rounding boundary (or by the fp32
+    error of the partial sums where the result cancels to nearly zero)."""
+    from yolo_from_scratch_amd import _lib as L
+    g = torch.Generator().manual_seed(n + cin + hw)
+    x = co.nhwc((torch.rand(n, cin, hw, hw, generator=g) - 0.3).to(DEV), torch.bfloat16)
+    w = co.nhwc(((torch.rand(cout, cin, k, k, generator=g) * 2 - 1) / (cin * k * k) ** 0.5).to(DEV))
+    b = ((torch.rand(cout, generator=g) * 2 - 1) * 0.1).to(DEV)
+    scale = (torch.rand(cout, generator=g) + 0.5).to(DEV)
+    w16, _ = co.weight_prep(w)
+    oh, ow = co.out_hw(hw, hw, k, s)
+    dz = co.nhwc(torch.randn(n, cout, oh, ow, generator=g).to(DEV), torch.bfloat16)
+    wd = co.nhwc(((torch.rand(cout, 256, k, k, generator=g) * 2 - 1) / (cout * k * k) ** 0.5).to(DEV))   # dgrad: 256 inputs
+    wt16 = co.weight_prep(wd)[1]
+    act = co.nhwc(torch.randn(n, 256, hw, hw, generator=g).to(DEV), torch.bfloat16)
+
+    def run():
+        outs = [co.conv_fwd(x, w16, b, s), co.conv_fwd_affine(x, w16, scale, b, s)]
+        names = [L.last_kernel()]
+        if s == 1:
+            outs += [co.conv_dgrad(dz, wt16, (hw, hw), 1, x_act=act), co.conv_dgrad(dz, wt16, (hw, hw), 1)]
+            names.append(L.last_kernel())
+        return [t.float().cpu() for t in outs], names
+    ref, _ = run()
+    L.set_knob("igemm_tile", 84)
+    try:
+        got, names = run()
+    finally:
+        L.set_knob("igemm_tile", 0)
+    assert all("epi4,ksplit" in nm for nm in names), names
+    for a, r in zip(got, ref):
+        err = (a - r).abs()
+        # (one ulp of the result, or of the fp32 partial sums where the result itself cancels to almost nothing)
+        bad = err > r.abs() * 2.0 ** -7 + 1e-5 * float(r.abs().max())
+        i = int((err * bad).argmax())
+        assert not bool(bad.any()), (f"{int(bad.sum())}/{bad.numel()} beyond one bf16 ulp; worst {float(a.flatten()[i])!r} vs "
+                                     f"{float(r.flatten()[i])!r} at {i}")
+        assert float((err > 0).float().mean()) < 0.02          # and the bulk is bit-identical

@@ -353,13 +353,22 @@ def test_config2_full_size_batch_properties():
         y = feat(xb)
         y.backward(dyb)
         return y.detach(), [p.grad.detach().float().clone() for p in feat.parameters()]
-    y_full, g_full = run(x, dy)
-    assert y_full.shape == (64, 1024, 7, 7)
-    g_sum = None
-    for i in range(0, 64, 16):
-        y_part, g_part = run(x[i:i + 16], dy[i:i + 16])
-        assert torch.equal(y_part, y_full[i:i + 16])
-        g_sum = g_part if g_sum is None else [a + b for a, b in zip(g_sum, g_part)]
+    # (the split-K form of the few-pixel layers picks its split from the pixel count, i.e. from the batch: without it
+    #  the property is exact, with it the sums are re-associated before the one bf16 rounding per layer)
+    from yolo_from_scratch_amd import conv_ops as _co
+    y_split, _ = run(x, dy)
+    _co.SPLIT_K = False
+    try:
+        y_full, g_full = run(x, dy)
+        assert y_full.shape == (64, 1024, 7, 7)
+        g_sum = None
+        for i in range(0, 64, 16):
+            y_part, g_part = run(x[i:i + 16], dy[i:i + 16])
+            assert torch.equal(y_part, y_full[i:i + 16])
+            g_sum = g_part if g_sum is None else [a + b for a, b in zip(g_sum, g_part)]
+    finally:
+        _co.SPLIT_K = True
+    assert float((y_split.float() - y_full.float()).abs().max()) <= 2e-2 * float(y_full.float().abs().max())
     # the activation gradients are rounded to bf16 per layer identically in both runs (same per-pixel arithmetic),
     # so only the fp32 accumulation order over pixels differs
     for a, b in zip(g_full, g_sum):

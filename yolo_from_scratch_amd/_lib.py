@@ -25,6 +25,7 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         for name in ("yfs_iou_xywh_workspace_bytes", "yfs_yolov1_loss_workspace_bytes", "yfs_mse_workspace_bytes",
                      "yfs_conv2d_wgrad_workspace_bytes", "yfs_sumsq_workspace_bytes",
+                     "yfs_conv2d_fwd_workspace_bytes", "yfs_conv2d_dgrad_workspace_bytes",
                      "yfs_conv2d_stem_wgrad_workspace_bytes", "yfs_single_box_loss_workspace_bytes",
                      "yfs_mask_to_boxes_workspace_bytes"):
             if hasattr(_lib, name):

@@ -47,6 +47,26 @@ def workspace(nbytes, device):
     return buf
 
 
+_split_bytes = {}
+SPLIT_K = True      # False: never hand the kernels a split-K workspace (every output is then independent of the batch size)
+
+
+def _split_workspace(op, n, h, w, cin, cout, k, stride, device):
+    """(scratch, bytes) for the split-K form of a forward / dgrad launch: (None, 0) for every shape that does not
+    split (all but the few-pixel, long-K layers).  The byte count per shape is cached, but not while a tile is forced
+    through the tuning knob (it depends on the knob then)."""
+    if not SPLIT_K:
+        return None, 0
+    key = (op, n, h, w, cin, cout, k, stride)
+    nbytes = _split_bytes.get(key)
+    if nbytes is None or L.get_knob("igemm_tile") != 0:
+        fn = L.lib().yfs_conv2d_fwd_workspace_bytes if op == "fwd" else L.lib().yfs_conv2d_dgrad_workspace_bytes
+        nbytes = fn(L.i64(n), L.c_int(h), L.c_int(w), L.c_int(cin), L.c_int(cout), L.c_int(k), L.c_int(stride))
+        if L.get_knob("igemm_tile") == 0:
+            _split_bytes[key] = nbytes
+    return (workspace(nbytes, device), nbytes) if nbytes else (None, 0)
+
+
 def weight_prep(w, want_w16=True, want_wt16=True):
     """fp32 weight (logical [Cout,Cin,K,K], channels_last) -> bf16 copy and transposed+flipped bf16 copy."""
     L.require_cuda(w)
@@ -130,9 +150,10 @@ def conv_fwd_affine(x, w16, scale, shift, stride=1, slope=0.1):
         raise L.YfsError(f"conv_fwd_affine: input has {cin} channels, weight expects {cin2}")
     oh, ow = out_hw(h, w, k, stride)
     y = _empty_nhwc(n, cout, oh, ow, x.device)
-    L.check(L.lib().yfs_conv2d_fwd_affine_bf16(L.ptr(x), L.ptr(w16), L.ptr(scale), L.ptr(shift), L.ptr(y), L.i64(n), L.c_int(h),
-                                               L.c_int(w), L.c_int(cin), L.c_int(cout), L.c_int(k), L.c_int(stride),
-                                               L.c_float(slope), L.stream()), "yfs_conv2d_fwd_affine_bf16")
+    ws, nbytes = _split_workspace("fwd", n, h, w, cin, cout, k, stride, x.device)
+    L.check(L.lib().yfs_conv2d_fwd_ws_bf16(L.ptr(x), L.ptr(w16), L.ptr(scale), L.ptr(shift), L.ptr(y), L.i64(n), L.c_int(h),
+                                           L.c_int(w), L.c_int(cin), L.c_int(cout), L.c_int(k), L.c_int(stride),
+                                           L.c_float(slope), L.ptr(ws), L.c_size(nbytes), L.stream()), "yfs_conv2d_fwd_ws_bf16")
     return y
 
 
@@ -146,9 +167,10 @@ def conv_fwd(x, w16, bias, stride=1, slope=0.1):
         raise L.YfsError(f"conv_fwd: input has {cin} channels, weight expects {cin2}")
     oh, ow = out_hw(h, w, k, stride)
     y = _empty_nhwc(n, cout, oh, ow, x.device)
-    L.check(L.lib().yfs_conv2d_fwd_bf16(L.ptr(x), L.ptr(w16), L.ptr(bias), L.ptr(y), L.i64(n), L.c_int(h), L.c_int(w),
-                                        L.c_int(cin), L.c_int(cout), L.c_int(k), L.c_int(stride), L.c_float(slope),
-                                        L.stream()), "yfs_conv2d_fwd_bf16")
+    ws, nbytes = _split_workspace("fwd", n, h, w, cin, cout, k, stride, x.device)
+    L.check(L.lib().yfs_conv2d_fwd_ws_bf16(L.ptr(x), L.ptr(w16), L.ptr(None), L.ptr(bias), L.ptr(y), L.i64(n), L.c_int(h),
+                                           L.c_int(w), L.c_int(cin), L.c_int(cout), L.c_int(k), L.c_int(stride),
+                                           L.c_float(slope), L.ptr(ws), L.c_size(nbytes), L.stream()), "yfs_conv2d_fwd_ws_bf16")
     return y
 
 
@@ -164,9 +186,11 @@ def conv_dgrad(dz, wt16, in_hw, stride=1, x_act=None, slope=0.1):
     dx = _empty_nhwc(n, cin, h, w, dz.device)
     if x_act is not None:
         x_act = nhwc(x_act, torch.bfloat16)
-    L.check(L.lib().yfs_conv2d_dgrad_bf16(L.ptr(dz), L.ptr(wt16), L.ptr(x_act), L.ptr(dx), L.i64(n), L.c_int(h),
-                                          L.c_int(w), L.c_int(cin), L.c_int(cout), L.c_int(k), L.c_int(stride),
-                                          L.c_float(slope), L.stream()), "yfs_conv2d_dgrad_bf16")
+    ws, nbytes = _split_workspace("dgrad", n, h, w, cin, cout, k, stride, dz.device)
+    L.check(L.lib().yfs_conv2d_dgrad_ws_bf16(L.ptr(dz), L.ptr(wt16), L.ptr(x_act), L.ptr(dx), L.i64(n), L.c_int(h),
+                                             L.c_int(w), L.c_int(cin), L.c_int(cout), L.c_int(k), L.c_int(stride),
+                                             L.c_float(slope), L.ptr(ws), L.c_size(nbytes), L.stream()),
+            "yfs_conv2d_dgrad_ws_bf16")
     return dx
 
 

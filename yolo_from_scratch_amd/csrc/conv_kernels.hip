@@ -46,7 +46,7 @@ __device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned o
 constexpr int kThreads = 256;
 constexpr int BK = 64;   // reduction depth per LDS tile (128 B rows)
 
-enum { EPI_BIAS_LEAKY = 0, EPI_MASK = 1, EPI_NONE = 2, EPI_POOL = 3 };
+enum { EPI_BIAS_LEAKY = 0, EPI_MASK = 1, EPI_NONE = 2, EPI_POOL = 3, EPI_PARTIAL = 4 };
 
 // n / d for 0 <= n < 2^31 with a host-prepared multiplier (Granlund-Montgomery round-up form).
 struct FastDiv {
@@ -88,6 +88,13 @@ struct IgemmArgs {
     int sub_s;                 // s
     int cls_ph[4], cls_pw[4];  // class parities, heaviest class (most taps) first
     int cls_end[4];            // running end of each class's logical block range (m-tiles of the class x ntiles)
+    // split-K (igemm8_kernel<EPI_PARTIAL>): the grid is ksplit copies of the tile grid, copy s reduces K-steps
+    // [s * ksteps_per_split, ...) and writes its fp32 tile to partial[s][M][NOUT]; splitk_epilogue_kernel sums the copies
+    // in index order and applies the epilogue.  ksplit = 1 everywhere else.
+    float* partial;
+    size_t partial_cap;        // bytes the caller's workspace holds (0 = none: no split-K)
+    int ksplit, ksteps_per_split;
+    int want_epi;              // the epilogue the split-K reduction applies (EPI_BIAS_LEAKY / EPI_MASK / EPI_NONE)
 };
 
 // XCD-aware, bijective remap: blocks that share blockIdx % 8 share an XCD (and its L2); give each XCD a
@@ -488,7 +495,12 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    const int logical = xcd_remap(blockIdx.x, g.mtiles * g.ntiles);
+    int logical = xcd_remap(blockIdx.x, g.mtiles * g.ntiles * (EPI == EPI_PARTIAL ? g.ksplit : 1));
+    int split = 0;
+    if (EPI == EPI_PARTIAL) {   // K-split outermost: the blocks of one split share its slice of the weights in L2
+        split = logical / (g.mtiles * g.ntiles);
+        logical -= split * (g.mtiles * g.ntiles);
+    }
     const int nt = logical % g.ntiles, mt = logical / g.ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
     const int Mc = g.M;
@@ -531,11 +543,21 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
     const unsigned ktot = (unsigned)(g.KH * g.KW * g.C);
     const unsigned wrow = (unsigned)(n0 + wave * 16 + (lane >> 3)) * ktot * 2 + chunk * 16;
     const int cchunks = g.C / BK;
-    const int nit = g.KH * g.KW * cchunks;
+    const int ktotal = g.KH * g.KW * cchunks;
+    // this block's K-steps: [ks0, kend) of the layer's ktotal (all of them unless EPI_PARTIAL)
+    const int ks0 = EPI == EPI_PARTIAL ? split * g.ksteps_per_split : 0;
+    const int kend = EPI == EPI_PARTIAL ? (ks0 + g.ksteps_per_split < ktotal ? ks0 + g.ksteps_per_split : ktotal) : ktotal;
+    const int nit = kend - ks0;
 
     // position of the tile the staging state describes: tile ts = (kh, kw, cc); xoff = this thread's source offsets
     // for that tap (recomputed when the tap changes)
-    int kh = 0, kw = 0, cc = 0, ts = 0;
+    int kh = 0, kw = 0, cc = 0, ts = ks0;
+    if (EPI == EPI_PARTIAL) {
+        const int tap0 = ks0 / cchunks;
+        cc = ks0 - tap0 * cchunks;
+        kh = tap0 / g.KW;
+        kw = tap0 - kh * g.KW;
+    }
     unsigned xoff[4];
     constexpr unsigned kOutside = 0xFFF00000u;
     auto tap_offsets = [&]() {
@@ -649,7 +671,7 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
         // phase B
         read_P(tb + B8_HALF, F1);
         advance();
-        if (ts < nit) {
+        if (ts < kend) {
             stage_W(0, BUF);
             stage_P(0, BUF);
             stage_W(1, BUF);
@@ -757,6 +779,12 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
                 const f32x4 v1 = *reinterpret_cast<const f32x4*>(rp + 16);
                 float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                 const long long o = (long long)m * g.NOUT + n0 + ec;
+                if (EPI == EPI_PARTIAL) {   // the raw fp32 sums of this block's K range; the epilogue runs in the reduction
+                    float* dst = g.partial + (long long)split * Mc * g.NOUT + o;
+                    *reinterpret_cast<f32x4*>(dst) = v0;
+                    *reinterpret_cast<f32x4*>(dst + 4) = v1;
+                    continue;
+                }
                 if (EPI == EPI_BIAS_LEAKY) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
@@ -799,9 +827,76 @@ int launch_igemm8(IgemmArgs& g, hipStream_t s, const char* name) {
     auto kern = igemm8_kernel<EPI, FP1, FW1>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, B8_LDS_IG);
     YFS_REQUIRE(e == hipSuccess, YFS_ERR_LAUNCH, "%s: cannot reserve %d bytes of LDS", name, B8_LDS_IG);
-    kern<<<dim3((unsigned)(g.mtiles * g.ntiles)), dim3(512), B8_LDS_IG, s>>>(g);
+    const int copies = EPI == EPI_PARTIAL ? g.ksplit : 1;
+    kern<<<dim3((unsigned)(g.mtiles * g.ntiles * copies)), dim3(512), B8_LDS_IG, s>>>(g);
     YFS_CHECK_LAUNCH(name);
     yfs_note_kernel("igemm8_kernel<%d,%d,epi%d>", 128 + FP1 * 32, 128 + FW1 * 64, EPI);
+    return YFS_OK;
+}
+
+// out[m][c] = epilogue(sum_s partial[s][m][c]), s in index order (fixed: deterministic), eight channels per thread.
+// Same epilogue arithmetic as the in-kernel one: fma(v, scale, bias) + LeakyReLU, or the activation-derivative mask.
+__global__ void __launch_bounds__(kThreads) splitk_epilogue_kernel(IgemmArgs g, long long n8) {
+    const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n8) return;
+    const long long o = i * 8;
+    const long long mn = (long long)g.M * g.NOUT;
+    float v[8];
+    {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(g.partial + o), b = *reinterpret_cast<const f32x4*>(g.partial + o + 4);
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    }
+    for (int sidx = 1; sidx < g.ksplit; ++sidx) {
+        const float* p = g.partial + sidx * mn + o;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+        v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3]; v[4] += b[0]; v[5] += b[1]; v[6] += b[2]; v[7] += b[3];
+    }
+    const int c = (int)(o % g.NOUT);
+    if (g.want_epi == EPI_BIAS_LEAKY) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float tv = __builtin_fmaf(v[j], g.scale ? g.scale[c + j] : 1.0f, g.bias[c + j]);
+            v[j] = tv > 0.0f ? tv : tv * g.slope;
+        }
+    } else if (g.want_epi == EPI_MASK) {
+        const bf16x8 av = *reinterpret_cast<const bf16x8*>(g.act + o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)av[j] > 0.0f ? v[j] : v[j] * g.slope;
+    }
+    bf16x8 ov;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ov[j] = (bf16_t)v[j];
+    *reinterpret_cast<bf16x8*>(g.out + o) = ov;
+}
+
+// Split-K plan of the 8-phase kernel for GEMMs with few pixels and a long reduction (feat.25-27: 3136 pixels x 1024
+// channels, K = 9216): 56 tiles of 224 x 256 cannot fill 256 CUs and the small tiles that can re-read the 19 MB of
+// weights once per 64 pixels (L2-bound at ~0.5 PFLOP/s).  Four K-splits of the big tile put 224 workgroups on the chip,
+// each streaming a quarter of the weights; the fp32 partial tiles (12.8 MB per split) are summed by
+// splitk_epilogue_kernel.  Returns the split count (1 = do not split).
+int igemm8_ksplit(const IgemmArgs& g, int rows, int force) {
+    const int ksteps = g.KH * g.KW * g.C / BK;
+    const long long tiles = yfs_cdiv(g.M, rows) * (g.NOUT / 256);
+    int ks = 1;
+    if (force == 84) ks = ksteps < 4 ? ksteps : 4;                       // tests: split whatever the shape
+    else if (tiles <= 128 && ksteps >= 64) ks = (int)std::min<long long>(256 / tiles, ksteps / 16);
+    if (ks < 2) return 1;
+    const int per = (int)yfs_cdiv(ksteps, ks);
+    return (int)yfs_cdiv(ksteps, per);
+}
+size_t igemm8_partial_bytes(const IgemmArgs& g, int ks) { return ks > 1 ? (size_t)ks * g.M * g.NOUT * sizeof(float) : 0; }
+
+int launch_igemm8_splitk(IgemmArgs& g, int ks, int want_epi, hipStream_t s, const char* name) {
+    const int ksteps = g.KH * g.KW * g.C / BK;
+    g.ksteps_per_split = (int)yfs_cdiv(ksteps, ks);
+    g.ksplit = (int)yfs_cdiv(ksteps, g.ksteps_per_split);
+    g.want_epi = want_epi;
+    const int rc = g.M % 224 == 0 ? launch_igemm8<EPI_PARTIAL, 3>(g, s, name) : launch_igemm8<EPI_PARTIAL, 4>(g, s, name);
+    if (rc) return rc;
+    const long long n8 = (long long)g.M * g.NOUT / 8;
+    splitk_epilogue_kernel<<<dim3((unsigned)yfs_cdiv(n8, kThreads)), dim3(kThreads), 0, s>>>(g, n8);
+    YFS_CHECK_LAUNCH(name);
+    yfs_note_kernel("igemm8_kernel<%d,256,epi4,ksplit%d>+splitk_epilogue<epi%d>", g.M % 224 == 0 ? 224 : 256, g.ksplit, want_epi);
     return YFS_OK;
 }
 
@@ -839,6 +934,12 @@ int dispatch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
     if (g.NOUT % 128 != 0) return launch_igemm<128, 64, 2, 2, 2, EPI, SUB>(g, s, name);
     // (igemm8_kernel packs a row's source coordinates into 16 bits each)
     const bool ok8 = g.NOUT % 256 == 0 && g.H < 16000 && g.W < 16000 && g.OH * g.s_mul < 16000 && g.OW * g.s_mul < 16000;
+    if constexpr (!SUB && EPI != EPI_POOL) {
+        if ((force == 0 || force == 84) && ok8 && g.partial_cap > 0) {
+            const int ks = igemm8_ksplit(g, g.M % 224 == 0 ? 224 : 256, force);
+            if (ks > 1 && igemm8_partial_bytes(g, ks) <= g.partial_cap) return launch_igemm8_splitk(g, ks, EPI, s, name);
+        }
+    }
     if constexpr (!SUB) {
         if (force == 8 && ok8) return launch_igemm8<EPI, 4>(g, s, name);
         if (force == 87 && ok8) return launch_igemm8<EPI, 3>(g, s, name);
@@ -902,20 +1003,69 @@ int check_conv_shape(const char* fn, int64_t N, int H, int W, int Cin, int Cout,
 
 }  // namespace
 
-YFS_API int yfs_conv2d_fwd_affine_bf16(const void* x, const void* w, const float* scale, const float* shift, void* y, int64_t N,
-                                       int H, int W, int Cin, int Cout, int K, int stride, float slope, void* stream) {
-    YFS_REQUIRE(x && w && shift && y, YFS_ERR_INVALID_ARG, "yfs_conv2d_fwd_affine_bf16: null pointer");
-    int rc = check_conv_shape("yfs_conv2d_fwd_affine_bf16", N, H, W, Cin, Cout, K, stride);
-    if (rc) return rc;
+namespace {
+void fwd_args(IgemmArgs& g, const void* x, const void* w, const float* scale, const float* shift, void* y, int64_t N, int H, int W,
+              int Cin, int Cout, int K, int stride, float slope) {
     const int pad = K / 2;
-    IgemmArgs g = {};
     g.x = (const bf16_t*)x; g.w = (const bf16_t*)w; g.bias = shift; g.scale = scale; g.out = (bf16_t*)y;
     g.N = (int)N; g.H = H; g.W = W; g.C = Cin;
     g.OH = (H + 2 * pad - K) / stride + 1; g.OW = (W + 2 * pad - K) / stride + 1; g.NOUT = Cout;
     g.KH = g.KW = K; g.PS = Cin; g.s_mul = stride; g.pad = pad; g.slope = slope;
     g.M = (int)(N * g.OH * g.OW);
     g.xbytes = (unsigned)(N * H * W * Cin * 2); g.wbytes = (unsigned)((int64_t)Cout * K * K * Cin * 2);
-    return dispatch_igemm<EPI_BIAS_LEAKY, false>(g, (hipStream_t)stream, "yfs_conv2d_fwd_affine_bf16");
+    g.ksplit = 1;
+}
+void dgrad_args(IgemmArgs& g, const void* dz, const void* wt, const void* x_act, void* dx, int64_t N, int H, int W, int Cin,
+                int Cout, int K, int stride, float slope) {
+    const int pad = K / 2;
+    g.x = (const bf16_t*)dz; g.w = (const bf16_t*)wt; g.act = (const bf16_t*)x_act; g.out = (bf16_t*)dx;
+    g.N = (int)N;
+    g.H = (H + 2 * pad - K) / stride + 1; g.W = (W + 2 * pad - K) / stride + 1; g.C = Cout;   // gathered tensor = dz
+    g.OH = H; g.OW = W; g.NOUT = Cin;
+    g.KH = g.KW = K; g.PS = Cout; g.s_mul = 1; g.pad = K - 1 - pad; g.sub_s = stride; g.slope = slope;
+    g.M = (int)(N * H * W);
+    g.xbytes = (unsigned)(N * g.H * g.W * Cout * 2); g.wbytes = (unsigned)((int64_t)Cout * K * K * Cin * 2);
+    g.ksplit = 1;
+}
+// bytes of fp32 partial tiles the split-K form would use for this GEMM (0: it does not split)
+size_t igemm_workspace_bytes(const IgemmArgs& g, bool sub) {
+    const bool ok8 = g.NOUT % 256 == 0 && g.H < 16000 && g.W < 16000 && g.OH * g.s_mul < 16000 && g.OW * g.s_mul < 16000;
+    const int force = yfs_knob(YFS_KNOB_IGEMM_TILE);
+    if (sub || !ok8 || !(force == 0 || force == 84)) return 0;
+    return igemm8_partial_bytes(g, igemm8_ksplit(g, g.M % 224 == 0 ? 224 : 256, force));
+}
+}  // namespace
+
+YFS_API size_t yfs_conv2d_fwd_workspace_bytes(int64_t N, int H, int W, int Cin, int Cout, int K, int stride) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || K <= 0 || stride <= 0) return 0;
+    IgemmArgs g = {};
+    fwd_args(g, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, Cin, Cout, K, stride, 0.0f);
+    return igemm_workspace_bytes(g, false);
+}
+
+YFS_API size_t yfs_conv2d_dgrad_workspace_bytes(int64_t N, int H, int W, int Cin, int Cout, int K, int stride) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || K <= 0 || stride <= 0) return 0;
+    IgemmArgs g = {};
+    dgrad_args(g, nullptr, nullptr, nullptr, nullptr, N, H, W, Cin, Cout, K, stride, 0.0f);
+    return igemm_workspace_bytes(g, stride != 1);
+}
+
+YFS_API int yfs_conv2d_fwd_ws_bf16(const void* x, const void* w, const float* scale, const float* shift, void* y, int64_t N,
+                                   int H, int W, int Cin, int Cout, int K, int stride, float slope, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    YFS_REQUIRE(x && w && shift && y, YFS_ERR_INVALID_ARG, "yfs_conv2d_fwd_bf16: null pointer");
+    int rc = check_conv_shape("yfs_conv2d_fwd_bf16", N, H, W, Cin, Cout, K, stride);
+    if (rc) return rc;
+    YFS_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, YFS_ERR_WORKSPACE, "yfs_conv2d_fwd_ws_bf16: workspace must be 16-byte aligned");
+    IgemmArgs g = {};
+    fwd_args(g, x, w, scale, shift, y, N, H, W, Cin, Cout, K, stride, slope);
+    g.partial = (float*)workspace; g.partial_cap = workspace ? workspace_bytes : 0;
+    return dispatch_igemm<EPI_BIAS_LEAKY, false>(g, (hipStream_t)stream, "yfs_conv2d_fwd_bf16");
+}
+
+YFS_API int yfs_conv2d_fwd_affine_bf16(const void* x, const void* w, const float* scale, const float* shift, void* y, int64_t N,
+                                       int H, int W, int Cin, int Cout, int K, int stride, float slope, void* stream) {
+    return yfs_conv2d_fwd_ws_bf16(x, w, scale, shift, y, N, H, W, Cin, Cout, K, stride, slope, nullptr, 0, stream);
 }
 
 YFS_API int yfs_conv2d_fwd_bf16(const void* x, const void* w, const float* bias, void* y, int64_t N, int H, int W,
@@ -939,23 +1089,25 @@ YFS_API int yfs_conv2d_fwd_pool_bf16(const void* x, const void* w, const float* 
     g.KH = g.KW = K; g.PS = Cin; g.s_mul = stride; g.pad = pad; g.slope = slope;
     g.M = (int)(N * g.OH * g.OW);
     g.xbytes = (unsigned)(N * H * W * Cin * 2); g.wbytes = (unsigned)((int64_t)Cout * K * K * Cin * 2);
+    g.ksplit = 1;
     return dispatch_igemm<EPI_POOL, false>(g, (hipStream_t)stream, "yfs_conv2d_fwd_pool_bf16");
 }
 
 YFS_API int yfs_conv2d_dgrad_bf16(const void* dz, const void* wt, const void* x_act, void* dx, int64_t N, int H, int W,
                                   int Cin, int Cout, int K, int stride, float slope, void* stream) {
+    return yfs_conv2d_dgrad_ws_bf16(dz, wt, x_act, dx, N, H, W, Cin, Cout, K, stride, slope, nullptr, 0, stream);
+}
+
+YFS_API int yfs_conv2d_dgrad_ws_bf16(const void* dz, const void* wt, const void* x_act, void* dx, int64_t N, int H, int W,
+                                     int Cin, int Cout, int K, int stride, float slope, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
     YFS_REQUIRE(dz && wt && dx, YFS_ERR_INVALID_ARG, "yfs_conv2d_dgrad_bf16: null pointer");
     int rc = check_conv_shape("yfs_conv2d_dgrad_bf16", N, H, W, Cout, Cin, K, stride);   // roles swap: reduce over Cout
     if (rc) return rc;
-    const int pad = K / 2;
+    YFS_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, YFS_ERR_WORKSPACE, "yfs_conv2d_dgrad_ws_bf16: workspace must be 16-byte aligned");
     IgemmArgs g = {};
-    g.x = (const bf16_t*)dz; g.w = (const bf16_t*)wt; g.act = (const bf16_t*)x_act; g.out = (bf16_t*)dx;
-    g.N = (int)N;
-    g.H = (H + 2 * pad - K) / stride + 1; g.W = (W + 2 * pad - K) / stride + 1; g.C = Cout;   // gathered tensor = dz
-    g.OH = H; g.OW = W; g.NOUT = Cin;
-    g.KH = g.KW = K; g.PS = Cout; g.s_mul = 1; g.pad = K - 1 - pad; g.sub_s = stride; g.slope = slope;
-    g.M = (int)(N * H * W);
-    g.xbytes = (unsigned)(N * g.H * g.W * Cout * 2); g.wbytes = (unsigned)((int64_t)Cout * K * K * Cin * 2);
+    dgrad_args(g, dz, wt, x_act, dx, N, H, W, Cin, Cout, K, stride, slope);
+    g.partial = (float*)workspace; g.partial_cap = workspace ? workspace_bytes : 0;
     hipStream_t s = (hipStream_t)stream;
     if (stride == 1) {
         return x_act ? dispatch_igemm<EPI_MASK, false>(g, s, "yfs_conv2d_dgrad_bf16")
