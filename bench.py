@@ -21,12 +21,12 @@ import os
 import sys
 import time
 
-# One process per GPU runs four or more HIP streams here (compute, weight gradients, gradient exchange, the collective
-# backend's own) and the HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues per process (4 on the
-# box).  In the one-GPU rehearsals of the N > 1 path the step stalled with 4 and with 8 queues and
-# ran every time with 16, so multi-rank runs raise a smaller setting to 16 (YFS_KEEP_HW_QUEUES=1 leaves it alone).
+# The gradient exchange owns no stream (dp.GradComm): a rank under RCCL drives three (compute, weight gradients, RCCL's own),
+# within the box's GPU_MAX_HW_QUEUES=4 hardware queues, so the driver's multi-GPU runs leave that setting alone.  Only the
+# one-GPU REHEARSAL of the N > 1 path (YFS_BENCH_ONE_GPU=1: gloo on CUDA tensors, which takes a fresh pool stream for every
+# collective) raises a smaller setting to 16, as in round 2; YFS_KEEP_HW_QUEUES=1 leaves it alone.
 # Read at HIP initialisation, hence set before torch is imported.
-if ((int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("YFS_BENCH_FORCE_DP") == "1")
+if (os.environ.get("YFS_BENCH_ONE_GPU") == "1" and int(os.environ.get("WORLD_SIZE", "1")) > 1
         and os.environ.get("YFS_KEEP_HW_QUEUES") != "1"):
     try:
         _q = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
@@ -457,6 +457,12 @@ def main():
     ap.add_argument("--compress-bf16", action="store_true", help="bf16 gradient buckets for the all-reduce")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON record: libraries that print there (RCCL writes a version banner at
+    # communicator set-up) are sent to stderr for the whole run, and the record goes out through the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -612,7 +618,7 @@ def main():
             rec["cpu_baseline"] = cpu_baseline_train()
         if force_dp:
             rec["rehearsal"] = "YFS_BENCH_FORCE_DP=1: one-rank RCCL group with the full gradient exchange forced on"
-        print(json.dumps(rec), flush=True)
+        os.write(json_fd, (json.dumps(rec) + "\n").encode())
     if multi:
         dist.barrier()
         dist.destroy_process_group()

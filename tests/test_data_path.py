@@ -101,8 +101,12 @@ def test_masks_to_boxes_channels_truncation_dims_and_single_mask_surface():
     np.testing.assert_array_equal(yd.mask_to_target_box(rgb[0]), yd.box_to_xywh_norm((3, 2, 5, 3), 24, 40))
     dots = _masks("dots", 30, 30, rng)
     assert len(yd.mask_to_boxes(dots)) == 225               # more components than the first guess of 64: asked again
+    # any dtype counts as "non-zero = object" (the reference's np.array(mask) != 0), negative and fractional values included
+    fl = np.where(flat, rng.choice([-2.5, 0.25, 7.0], size=flat.shape), 0.0).astype(np.float32)
+    assert yd.mask_to_boxes(fl) == ref
+    assert yd.mask_to_boxes(torch.from_numpy(flat.astype(np.int64)).cuda()) == ref
     with pytest.raises(yd.L.YfsError):
-        yd.masks_to_boxes(torch.zeros(2, 4, 4, dtype=torch.float32, device="cuda"))
+        yd.masks_to_boxes(torch.zeros(4, 4, dtype=torch.uint8, device="cuda"))     # not a batch
 
 
 @pytest.mark.gpu

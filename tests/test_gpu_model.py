@@ -307,7 +307,7 @@ def test_deferred_linear_gradient_under_data_parallel_exchange(monkeypatch):
     from yolo_from_scratch_amd import dp
     world = 2
 
-    def fake_all_gather(outs, t, group=None):
+    def fake_all_gather(outs, t, group=None, async_op=False):
         for o in outs:
             o.copy_(t)
 

@@ -160,7 +160,7 @@ def test_backbone_model_under_data_parallel_exchange(monkeypatch):
     world = 2
     calls = {"ar": 0, "ag": 0}
 
-    def fake_all_gather(outs, t, group=None):
+    def fake_all_gather(outs, t, group=None, async_op=False):
         calls["ag"] += 1
         for o in outs:
             o.copy_(t)

@@ -77,7 +77,7 @@ def test_exchange_on_rccl_in_a_one_rank_group_changes_nothing(rccl_group):
     assert comm.world == 1 and comm.active
     got = _run(comm)
     assert len(comm.buckets) >= 8 and any(e - s < (2 << 20) for s, e in comm.buckets)
-    assert comm.stream is not None                       # the RCCL branch: collectives behind the exchange stream
+    assert comm.exchange_streams == 0                    # the collectives ride on RCCL's own stream: none added here
     assert torch.equal(got.flat_p, base.flat_p) and torch.equal(got.flat_m, base.flat_m)
     assert torch.equal(got.flat_p16, base.flat_p16)
     # bf16 buckets: the gradients are rounded to bf16 on the wire, nothing else may differ

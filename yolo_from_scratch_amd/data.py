@@ -15,17 +15,20 @@ _ws = {}
 
 
 def masks_to_boxes(masks, max_boxes=64, dims=None):
-    """masks: [N,H,W] or [N,H,W,CH] uint8/bool, CUDA tensor (or numpy array: uploaded), non-zero = object.
+    """masks: [N,H,W] or [N,H,W,CH], any integer / bool / float dtype, CUDA tensor (or numpy array: uploaded), non-zero = object.
+    This batched call is the fast path; ``mask_to_boxes`` / ``mask_to_target_box`` below are per-sample conveniences with
+    the reference's signatures (one upload, seven launches and one host read each: not for a DataLoader's inner loop).
     -> (boxes int32 [N,max_boxes,4] as (x_min, y_min, x_max, y_max) in label order, rows past count undefined;
         count int32 [N]; best_box int32 [N,4] (-1 for an empty mask); best_xywh fp32 [N,4]) as :98-119 and :195-196.
     ``dims`` [N,2] = (H_i, W_i): the original sizes of masks that were zero-padded to a common H x W."""
     if not torch.is_tensor(masks):
         masks = torch.from_numpy(np.ascontiguousarray(masks)).cuda()
     L.require_cuda(masks)
-    if masks.dtype == torch.bool:
-        masks = masks.to(torch.uint8)
-    if masks.dtype != torch.uint8 or masks.dim() not in (3, 4):
-        raise L.YfsError(f"masks_to_boxes: expected uint8 [N,H,W] or [N,H,W,CH], got {masks.dtype} {tuple(masks.shape)}")
+    if masks.dim() not in (3, 4):
+        raise L.YfsError(f"masks_to_boxes: expected [N,H,W] or [N,H,W,CH], got {tuple(masks.shape)}")
+    if masks.dtype != torch.uint8:
+        # any dtype counts as "non-zero = object", as the reference's np.array(mask) != 0 does (:103); one pass on the device
+        masks = (masks != 0).to(torch.uint8)
     masks = masks.contiguous()
     n, h, w = masks.shape[:3]
     ch = masks.shape[3] if masks.dim() == 4 else 1

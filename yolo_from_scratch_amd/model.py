@@ -468,7 +468,7 @@ class _LinearFn(torch.autograd.Function):
             # FlatSGD takes this layer's step from the factors of its gradient (train.FlatSGD._step_with_deferred);
             # with several ranks the factors of all ranks are gathered and the mean gradient is 1/world of their product
             if multi:
-                xa, da = comm.gather_factors(x16, dy16)
+                xa, da = comm.gather_factors(x16, dy16, owner=weight)
                 weight._yfs_factors = (xa, da, 1.0 / comm.world)
             else:
                 weight._yfs_factors = (x16, dy16, 1.0)
