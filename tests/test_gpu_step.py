@@ -40,10 +40,16 @@ class _OracleV1Loss(torch.autograd.Function):
 def test_two_full_steps_match_the_oracle_step(head):
     """Two full steps at 64x64, batch 8, dropout off: feat + fc with (a) the reference's own head and loss (4 outputs,
     MSE, :255-264, :377) and (b) the 1470-output head with the composite loss.  Updated parameters and momentum
-    buffers against oracle.model_ref.train_step (torch-CPU fp32).  Tolerance: the step is lr * (clipped gradient +
-    weight decay), and the gradient has passed 24 bf16 layers twice, so the UPDATE (p_after - p_before) is compared at
-    the bf16 end-to-end tolerance this suite uses for the forward (4e-2, test_gpu_model.py) relaxed to 8e-2 for the
-    backward chain, per parameter group with a meaningful update; losses at 4e-2."""
+    buffers against oracle.model_ref.train_step (torch-CPU fp32), per tensor, on the UPDATE p_after - p_before (the
+    parameters themselves are dominated by their initial values and agree to 1e-4):
+      * losses: 5e-4 relative (measured 5e-5: the forward's bf16 rounding averages out over the outputs);
+      * weight tensors: 1e-2, north_star's figure for bf16 conv (measured worst 5.1e-3, fc.1.weight);
+      * bias tensors: 8e-2.  That is the floor for them, not slack: a bias gradient is the plain sum of dz over all
+        pixels of the batch, dz is rounded to bf16 once per layer, and in the layers behind the last pool (feat.21-24, 4x4
+        maps) that sum cancels to a few per cent of the summed magnitudes, so the 2^-9 relative rounding of the terms
+        shows up amplified by the cancellation ratio (measured worst 4.4e-2, feat.23.0.bias; every other bias <= 2e-2).
+        The weight gradients of the same layers have no such cancellation (x is a LeakyReLU output, mostly one sign).
+    The assertion message lists the worst tensor of each class."""
     head_out = 4 if head == "mse4" else 1470
     params = model_ref.init_params(seed=0, head_out=head_out, in_hw=64)
     torch.manual_seed(0)
@@ -72,19 +78,25 @@ def test_two_full_steps_match_the_oracle_step(head):
         loss = loss_gpu(net(x.to(DEV)), tgt.to(DEV))
         loss.backward()
         opt.step()
-        assert abs(float(loss) - lo) <= 4e-2 * abs(lo) + 1e-4, (step, float(loss), lo)
+        assert abs(float(loss) - lo) <= 5e-4 * abs(lo) + 1e-6, (step, float(loss), lo)
     sd = {k: v.detach().cpu().contiguous() for k, v in net.state_dict().items()}
     checked = 0
+    worst = {"weight": (0.0, None), "bias": (0.0, None), "momentum weight": (0.0, None), "momentum bias": (0.0, None)}
+    tol = {"weight": 1e-2, "bias": 8e-2, "momentum weight": 1e-2, "momentum bias": 8e-2}
     for i, k in enumerate(names):
         upd_ref = params[k] - before[k]
         upd = sd[k] - before[k]
         if float(upd_ref.norm()) < 1e-7:
             continue
-        assert _rel(upd, upd_ref) < 8e-2, (k, _rel(upd, upd_ref))
+        kind = "bias" if k.endswith("bias") else "weight"
         o, n = opt.offsets[i]
         m_gpu = torch.as_strided(opt.flat_m, net.get_parameter(k).shape, net.get_parameter(k).stride(), o).cpu().contiguous()
-        assert _rel(m_gpu, bufs[k]) < 8e-2, ("momentum", k)
+        for cls, err in ((kind, _rel(upd, upd_ref)), ("momentum " + kind, _rel(m_gpu, bufs[k]))):
+            if err > worst[cls][0]:
+                worst[cls] = (err, k)
         checked += 1
+    report = "; ".join(f"{c}: {e:.4f} at {k} (tolerance {tol[c]})" for c, (e, k) in worst.items())
+    assert all(worst[c][0] < tol[c] for c in tol), report
     assert checked >= 40
     # and the parameters themselves (dominated by their initial values) agree far more tightly
     for k in names:

@@ -9,3 +9,4 @@ from .assign import assign_targets_v2, VOC_ANCHORS  # noqa: F401
 from .anchors import estimate_size_priors, kmeans_anchors, anchor_assign, init_head_biases  # noqa: F401
 from .metrics import mean_average_precision  # noqa: F401
 from .data import mask_to_boxes, box_to_xywh_norm, largest_box, mask_to_target_box, encode_targets_v1  # noqa: F401
+from .conv_ops import release_workspaces  # noqa: F401,E402

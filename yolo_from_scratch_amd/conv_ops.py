@@ -67,6 +67,15 @@ def _split_workspace(op, n, h, w, cin, cout, k, stride, device):
     return (workspace(nbytes, device), nbytes) if nbytes else (None, 0)
 
 
+def release_workspaces():
+    """Drop the cached scratch buffers of this module and of data.py (one per device and stream that ever launched a
+    kernel needing one; they are kept for reuse and otherwise live until the process ends).  Safe between steps: the
+    next launch allocates again."""
+    from . import data
+    _ws_cache.clear()
+    data._ws.clear()
+
+
 def weight_prep(w, want_w16=True, want_wt16=True):
     """fp32 weight (logical [Cout,Cin,K,K], channels_last) -> bf16 copy and transposed+flipped bf16 copy."""
     L.require_cuda(w)

@@ -3,7 +3,7 @@
 // The loss slots in where the reference calls loss_fn(preds, yb) (yolo_toy_regressor_torch.py:329).
 // Built with -ffp-contract=off so the responsible-box choice (argmax IoU) matches the CPU oracle.
 #include "yfs_common.h"
-#include <mutex>
+#include <atomic>
 
 // Scratch of yfs_yolov1_loss_noalloc_f32 (the entry point for callers that cannot allocate): the per-block partial
 // sums of the four loss terms.  One copy per GPU the library runs on, held until the process ends.  Host code never
@@ -305,8 +305,7 @@ YFS_API int yfs_yolov1_loss_fwd_bwd_f32(const float* pred, const float* target, 
 // ---- the same loss for callers that cannot allocate ------------------------------------------------------------------
 namespace {
 constexpr int kMaxDevices = 64;
-std::mutex g_scratch_mu;
-float* g_scratch_ptr[kMaxDevices] = {};   // device address of `scratch` on each GPU (every GPU holds its own copy)
+std::atomic<float*> g_scratch_ptr[kMaxDevices];   // device address of `scratch` on each GPU (every GPU holds its own copy)
 
 // Device address of this GPU's copy of `scratch`; resolved once per device, with that device current.
 int noalloc_scratch(float** out) {
@@ -314,15 +313,18 @@ int noalloc_scratch(float** out) {
     hipError_t e = hipGetDevice(&dev);
     YFS_REQUIRE(e == hipSuccess && dev >= 0 && dev < kMaxDevices, YFS_ERR_LAUNCH,
                 "yfs_yolov1_loss_noalloc_f32: hipGetDevice failed or device index %d out of range", dev);
-    std::lock_guard<std::mutex> lock(g_scratch_mu);
-    if (!g_scratch_ptr[dev]) {
+    // no lock on the call path: the address of a device's copy never changes, so racing first calls on one device resolve
+    // the same value and either store is fine
+    float* known = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!known) {
         void* p = nullptr;
         e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
         YFS_REQUIRE(e == hipSuccess && p, YFS_ERR_LAUNCH, "yfs_yolov1_loss_noalloc_f32: hipGetSymbolAddress failed: %s",
                     hipGetErrorString(e));
-        g_scratch_ptr[dev] = (float*)p;
+        known = (float*)p;
+        g_scratch_ptr[dev].store(known, std::memory_order_release);
     }
-    *out = g_scratch_ptr[dev];
+    *out = known;
     return YFS_OK;
 }
 }  // namespace
