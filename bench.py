@@ -127,17 +127,23 @@ BATCH = 64
 LOSS_BYTES_PER_IMG = 17640    # read pred + read target + write grad, 3 x 1470 x 4
 ASSIGN_BYTES_PER_IMG = 32750  # gts 640 + decoded preds 13,520 + masks 1,690 + targets 16,900
 NMS_BYTES_PER_IMG = 108160    # raw head 84,500 + boxes/score/class 20,280 + kept indices 3,380
-# HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled
-# per the gfx950 note of MI355X_MICROARCH.md; profiles/r02/pmc_traffic_hbm_kernels.txt), at the sub-benchmarks' own sizes.
-# bench.py cannot run rocprofv3 on itself, so these are the committed measurements, not live values.
-# nms: decode launch 104.8 MB + NMS launch 32.1 MB (it re-reads score / class / passing boxes; 4-B reads are over-counted
-# by the doubling, the true figure lies between 126 and 137 MB).
-PMC_TRAFFIC_BYTES = {"nms": 137.0e6, "loss": 1129.5e6, "assign": 264.2e6}
-# MFMA utilisation of the conv kernels from the PMC counters (SQ_VALU_MFMA_BUSY_CYCLES over the active cycles of all SIMDs;
-# rocprofv3 --pmc passes over tools/conv_bench.py, profiles/r02/conv_pmc_summary.txt).  Committed measurements, as above.
-PMC_MFMA_BUSY = {"igemm8_kernel (3x3 forward / dgrad)": [0.52, 0.60], "wgrad8_kernel (3x3 weight gradient)": [0.49, 0.54],
-                 "stem_pool_kernel": 0.49, "igemm8_kernel<mask, 256 rows, 192 channels> (feat.2 dgrad)": 0.46,
-                 "source": "profiles/r02/conv_pmc_summary.txt"}
+# HBM bytes per launch (roofline.traffic of the HBM-bound sets) and MFMA utilisation of the conv kernels come from the PMC
+# counters.  bench.py cannot run rocprofv3 on itself, so they are COMMITTED measurements at the sub-benchmarks' own sizes:
+# the "#json" line that tools/pmc_traffic.py / tools/pmc_summarize.py write at the end of profiles/rNN/
+# pmc_traffic_hbm_kernels.txt and conv_pmc_summary.txt (FETCH_SIZE / WRITE_SIZE in separate --pmc passes, FETCH_SIZE
+# doubled per the gfx950 note of MI355X_MICROARCH.md; SQ_VALU_MFMA_BUSY_CYCLES over the active cycles of all SIMDs).  The
+# newest round's file is read at run time and the record names it with its git blob hash, so a stale file shows.
+def committed_pmc(name):
+    """-> (values from the file's #json line, {"file", "git_blob"}) of the newest profiles/rNN/<name>, or (None, None)."""
+    import glob
+    import hashlib
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*", name)), reverse=True):
+        data = open(path, "rb").read()
+        for line in reversed(data.decode("utf-8", "replace").splitlines()):
+            if line.startswith("#json "):
+                blob = hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()      # = git hash-object
+                return json.loads(line[6:]), {"file": os.path.relpath(path, ROOT), "git_blob": blob}
+    return None, None
 
 
 def conv_flops_table(model, batch, hw=448):
@@ -287,7 +293,7 @@ def nms_bench(device, iters=20):
     ms = e0.elapsed_time(e1) / iters
     out = {"metric": "NMS images/sec (decode + IoU + class-wise NMS, 13x13x5 anchors, C=20, batch 1024)",
            "value": round(N / (ms * 1e-3), 1), "unit": "images/s", "ms_per_batch": round(ms, 4), "dtype": "f32",
-           "roofline": _hbm_record(N * NMS_BYTES_PER_IMG, ms, PMC_TRAFFIC_BYTES["nms"])}
+           "roofline": _hbm_record(N * NMS_BYTES_PER_IMG, ms, "nms")}
     return out
 
 
@@ -304,11 +310,12 @@ def _time_ms(fn, iters, warm=3):
     return e0.elapsed_time(e1) / iters
 
 
-def _hbm_record(nbytes, ms, traffic=None):
+def _hbm_record(nbytes, ms, traffic_key=None):
     gbs = nbytes / (ms * 1e-3) / 1e9
+    vals, src = committed_pmc("pmc_traffic_hbm_kernels.txt") if traffic_key else (None, None)
     return {"bound": "hbm", "achieved": round(gbs, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-            "frac": round(gbs / PEAK_HBM_GBS, 5), "traffic": traffic,
-            "traffic_source": "profiles/r02/pmc_traffic_hbm_kernels.txt (bytes per launch)" if traffic else None}
+            "frac": round(gbs / PEAK_HBM_GBS, 5), "traffic": float(vals[traffic_key]) if vals and vals.get(traffic_key) else None,
+            "traffic_source": src}
 
 
 def loss_bench(device, N=65536):
@@ -331,7 +338,7 @@ def loss_bench(device, N=65536):
     ms = _time_ms(run, 20)
     return {"metric": "fused YOLOv1 loss + gradient images/sec (S=7 B=2 C=20, batch %d)" % N,
             "value": round(N / (ms * 1e-3), 1), "unit": "images/s", "ms_per_batch": round(ms, 4), "dtype": "f32",
-            "roofline": _hbm_record(N * LOSS_BYTES_PER_IMG, ms, PMC_TRAFFIC_BYTES["loss"] if N == 65536 else None)}
+            "roofline": _hbm_record(N * LOSS_BYTES_PER_IMG, ms, "loss" if N == 65536 else None)}
 
 
 def assign_bench(device, N=8192, S=13, G=32):
@@ -344,7 +351,7 @@ def assign_bench(device, N=8192, S=13, G=32):
     ms = _time_ms(lambda: y.assign_targets_v2(gt, anchors, S, pred, 0.6), 20)
     return {"metric": "YOLOv2 target assignment images/sec (S=13, A=5, G=32, batch %d)" % N,
             "value": round(N / (ms * 1e-3), 1), "unit": "images/s", "ms_per_batch": round(ms, 4), "dtype": "f32",
-            "roofline": _hbm_record(N * ASSIGN_BYTES_PER_IMG, ms, PMC_TRAFFIC_BYTES["assign"] if (N, S, G) == (8192, 13, 32) else None)}
+            "roofline": _hbm_record(N * ASSIGN_BYTES_PER_IMG, ms, "assign" if (N, S, G) == (8192, 13, 32) else None)}
 
 
 def mask_boxes_bench(device, N=64, H=375, W=500, cpu_sample=6):
@@ -596,7 +603,7 @@ def main():
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
                          "algorithmic_tflop_per_step": round(conv_flops / 1e12, 4), "conv_ms_per_step": round(conv_ms, 3),
-                         "mfma_busy_pmc": PMC_MFMA_BUSY,
+                         "mfma_busy_pmc": dict(zip(("kernels", "source"), committed_pmc("conv_pmc_summary.txt"))),
                          "measured_over": "%d extra steps with the weight-gradient stream off (non-overlapping "
                                           "brackets); the headline value runs with it on" % rsteps,
                          "kernels": kernels},

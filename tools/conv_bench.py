@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Per-layer micro-benchmark of the conv kernel set at BASELINE config 2 shapes (batch 64, 448x448).
-    python tools/conv_bench.py [--ops fwd,dgrad,wgrad] [--layers 2,7,18] [--iters 10] [--batch 64]
-Prints TFLOP/s per layer and op (HIP-event timing, random bf16 data)."""
+    python tools/conv_bench.py [--ops fwd,dgrad,wgrad | step] [--layers 2,7,18] [--iters 10] [--batch 64]
+Prints TFLOP/s per layer and op (HIP-event timing, random bf16 data).  --ops step: per layer exactly the launches the
+training step makes (pool-fused forward for feat.0/2/7/18, the stem's weight gradient from the pooled side, no dgrad
+for the stem), so a profile of this run shows the step's kernels and nothing else."""
 import argparse
 import os
 import sys
@@ -35,6 +37,10 @@ def main():
     L.set_knob("wgrad_tile", a.wgrad_tile)
     L.set_knob("wgrad_splits", a.wgrad_splits)
     dev = "cuda:0"
+    step_ops = a.ops == "step"
+    if step_ops:
+        a.ops = "fwd,fwdpool,dgrad,wgrad,wgradpool"
+    POOLED = (0, 2, 7, 18)
     tot = {op: 0.0 for op in a.ops.split(",")}
     for li in [int(v) for v in a.layers.split(",")]:
         cin, cout, k, s, hw = LAYERS[li]
@@ -54,6 +60,8 @@ def main():
                            ("fwdpool", lambda: co.stem_fwd_pool(xs, w2, b, oh, ow)), ("wgrad", lambda: co.stem_wgrad(xs, dz)),
                            ("wgradpool", lambda: co.stem_wgrad_pool(xs, gp, pidx, yp))):
                 if op != "s2d" and op not in tot:
+                    continue
+                if step_ops and op in ("fwd", "wgrad"):
                     continue
                 for _ in range(2):
                     fn()
@@ -80,6 +88,8 @@ def main():
         for op in a.ops.split(","):
             if op == "wgradpool" or (op == "fwdpool" and oh % 2):
                 continue          # stem only / odd output: no fused pool
+            if step_ops and op == ("fwd" if li in POOLED else "fwdpool"):
+                continue
             fn = {"fwd": lambda: co.conv_fwd(x, w16, b, s), "fwdpool": lambda: co.conv_fwd_pool(x, w16, b, s),
                   "dgrad": lambda: co.conv_dgrad(dz, wt16, (hw, hw), s, x_act=x),
                   "wgrad": lambda: co.conv_wgrad(x, dz, k, s)}[op]

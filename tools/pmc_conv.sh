@@ -3,9 +3,9 @@
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/r2/${PMC_TAG:-pmc5}
+OUT=$R/gpurun_out/r3/${PMC_TAG:-pmc}
 mkdir -p $OUT
-CMD="python3 $R/tools/conv_bench.py --iters 3 --ops fwdpool,fwd,dgrad,wgrad --layers 0,2,7,18,24"
+CMD="python3 $R/tools/conv_bench.py --iters 3 --ops step --layers 0,2,5,7,9,18,24,26"
 i=0
 for ctrs in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \
             "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS GRBM_GUI_ACTIVE" \

@@ -50,3 +50,6 @@ if "decode_grid_kernel" in tot and "nms_kernel" in tot:
     print(f"\ndecode + NMS per 1024 images: {tot['decode_grid_kernel'] + tot['nms_kernel']:.1f} MB; algorithmic "
           f"{1024 * 108160 / 1e6:.1f} MB (108,160 B/img: raw head in, boxes/score/class/keep out); the NMS launch re-reads "
           f"score, class and the passing boxes that the decode launch wrote (L2/MALL hits do not count as HBM traffic).")
+print("#json " + __import__("json").dumps({"nms": round((tot.get("decode_grid_kernel", 0) + tot.get("nms_kernel", 0)) * 1e6),
+                                             "loss": round(tot.get("yolov1_loss_kernel", 0) * 1e6),
+                                             "assign": round(tot.get("assign_v2_kernel", 0) * 1e6)}))     # bytes per launch; read by bench.py
