@@ -469,3 +469,4 @@ def test_split_k_form_of_the_8phase_kernel_matches_the_unsplit_kernels(n, cin, c
         assert not bool(bad.any()), (f"{int(bad.sum())}/{bad.numel()} beyond one bf16 ulp; worst {float(a.flatten()[i])!r} vs "
                                      f"{float(r.flatten()[i])!r} at {i}")
         assert float((err > 0).float().mean()) < 0.02          # and the bulk is bit-identical
+
