@@ -486,13 +486,8 @@ __device__ long long yfs_ig8_dbg[8];
 #endif
 // FW1 = channel fragments per wave in the SECOND weight half-tile: 2 -> 256-channel tile, 1 -> 192-channel tile (W1 holds
 // 64 rows, its MFMA blocks are half as long): feat.2's dgrad writes 192 channels.
-// M32 = 1: the same schedule on v_mfma_f32_32x32x16_bf16 (half the operand register reads per FLOP; 256 x 256 tile only: a
-// wave's 48 rows of the 224-row tile's second half and its 16 channels of the 192-channel tile are no multiples of 32).
-// Experiment of round 3, reachable through the tuning knob only.
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-template <int EPI, int FP1, int FW1 = 2, int M32 = 0>
+template <int EPI, int FP1, int FW1 = 2>
 __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
-    static_assert(!M32 || (FP1 == 4 && FW1 == 2 && EPI != EPI_POOL), "32x32x16 form: full 256 x 256 tile, no pool epilogue");
     constexpr int BM = 128 + FP1 * 32, BN = 128 + FW1 * 64, NT = 512;
     IG8_T(0);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -605,12 +600,6 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
     f32x4 acc[2][2][2][4];   // [pixel half][weight half][channel fragment][pixel fragment]
 #pragma unroll
     for (int i = 0; i < 32; ++i) (&acc[0][0][0][0])[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // M32: [pixel half][weight half][32-pixel fragment]; D[i] = out[pixel (lane & 31)][channel (i/4)*8 + (lane>>5)*4 + i%4]
-    f32x16 acc32[2][2][2];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) (&acc32[0][0][0])[i][j] = 0.f;
 
     const int frow = lane & 15, fk = lane >> 4;
     bf16x8 pf[4][2], w0f[2][2], w1f[2][2];
@@ -639,28 +628,6 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
             for (int a = 0; a < NA; ++a)
 #pragma unroll
                 for (int b = 0; b < NF; ++b) c[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a][ks], pf[b][ks], c[a][b], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-    };
-    // M32 fragments: lane = (row lane & 31, K-half lane >> 5) of a 32-row x 16-deep operand; four 16-deep steps per K-step
-    bf16x8 pf32[2][4], w0f32[4], w1f32[4];
-    const int r32 = lane & 31, k32 = lane >> 5;
-    auto read_P32 = [&](const unsigned char* hb) {
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-                pf32[b][kk] = *reinterpret_cast<const bf16x8*>(hb + swz(wm * 64 + b * 32 + r32, kk * 2 + k32));
-    };
-    auto read_W32 = [&](const unsigned char* hb, bf16x8 (&wf)[4]) {
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) wf[kk] = *reinterpret_cast<const bf16x8*>(hb + swz(wn * 32 + r32, kk * 2 + k32));
-    };
-    auto mfma32 = [&](f32x16 (&c)[2], const bf16x8 (&wf)[4]) {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) c[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk], pf32[b][kk], c[b], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
     auto lgkm0 = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
@@ -692,29 +659,17 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
         constexpr int BUF = decltype(buf_tag)::value;
         const unsigned char* tb = smem + BUF * B8_BUF;
         // phase A
-        if constexpr (M32) {
-            read_W32(tb + 2 * B8_HALF, w0f32);
-            read_P32(tb);
-            read_W32(tb + 3 * B8_HALF, w1f32);
-        } else {
-            read_W(tb + 2 * B8_HALF, w0f, A2);
-            read_P(tb, F4);
-            read_W(tb + 3 * B8_HALF, w1f, A1);
-        }
+        read_W(tb + 2 * B8_HALF, w0f, A2);
+        read_P(tb, F4);
+        read_W(tb + 3 * B8_HALF, w1f, A1);
         if (t + 1 < nit) stage_P(1, BUF ^ 1);
         lgkm0();
         bar();
-        if constexpr (M32) {
-            mfma32(acc32[0][0], w0f32);
-            mfma32(acc32[0][1], w1f32);
-        } else {
-            mfma16(acc[0][0], w0f, F4, A2);
-            mfma16(acc[0][1], w1f, F4, A1);
-        }
+        mfma16(acc[0][0], w0f, F4, A2);
+        mfma16(acc[0][1], w1f, F4, A1);
         bar();
         // phase B
-        if constexpr (M32) read_P32(tb + B8_HALF);
-        else read_P(tb + B8_HALF, F1);
+        read_P(tb + B8_HALF, F1);
         advance();
         if (ts < kend) {
             stage_W(0, BUF);
@@ -726,13 +681,8 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
         }
         lgkm0();
         bar();
-        if constexpr (M32) {
-            mfma32(acc32[1][1], w1f32);
-            mfma32(acc32[1][0], w0f32);
-        } else {
-            mfma16(acc[1][1], w1f, F1, A1);
-            mfma16(acc[1][0], w0f, F1, A2);
-        }
+        mfma16(acc[1][1], w1f, F1, A1);
+        mfma16(acc[1][0], w0f, F1, A2);
         bar();
     };
     int t = 0;
@@ -770,19 +720,6 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
         const int PR = NF * 16;                                       // rows per slab
         const int rbase = ph * 128;                                   // first tile row of slab 0; slab 1 follows at + PR
         unsigned char* const myslab = smem + wm * SLAB;
-        if constexpr (M32) {
-#pragma unroll
-            for (int wh = 0; wh < 2; ++wh)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int ch = wh * 128 + wn * 32 + q * 8 + k32 * 4;
-                        const f32x16& c = acc32[ph][wh][b];
-                        *reinterpret_cast<f32x4*>(myslab + (b * 32 + r32) * B8_EPI_STRIDE + ch * 4) =
-                            (f32x4){c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]};
-                    }
-        } else {
 #pragma unroll
         for (int wh = 0; wh < 2; ++wh)
 #pragma unroll
@@ -793,7 +730,6 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
                     const int ch = wh * 128 + wn * (wh == 1 ? FW1 * 16 : 32) + a * 16 + fk * 4;
                     *reinterpret_cast<f32x4*>(myslab + (b * 16 + frow) * B8_EPI_STRIDE + ch * 4) = acc[ph][wh][a][b];
                 }
-        }
         __syncthreads();
         if (EPI == EPI_POOL) {
             // one item per thread and slab: (window, 8 channels); see igemm_kernel for the pooling rule
@@ -882,19 +818,19 @@ extern "C" __attribute__((visibility("default"))) int yfs_debug_ig8_times(long l
 }
 namespace {
 #endif
-template <int EPI, int FP1, int FW1 = 2, int M32 = 0>
+template <int EPI, int FP1, int FW1 = 2>
 int launch_igemm8(IgemmArgs& g, hipStream_t s, const char* name) {
     g.mtiles = (int)yfs_cdiv(g.M, 128 + FP1 * 32);
     g.ntiles = g.NOUT / (128 + FW1 * 64);
     g.div_hw = make_fastdiv(EPI == EPI_POOL ? (unsigned)((g.OH / 2) * (g.OW / 2)) : (unsigned)(g.OH * g.OW));
     g.div_w = make_fastdiv(EPI == EPI_POOL ? (unsigned)(g.OW / 2) : (unsigned)g.OW);
-    auto kern = igemm8_kernel<EPI, FP1, FW1, M32>;
+    auto kern = igemm8_kernel<EPI, FP1, FW1>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, B8_LDS_IG);
     YFS_REQUIRE(e == hipSuccess, YFS_ERR_LAUNCH, "%s: cannot reserve %d bytes of LDS", name, B8_LDS_IG);
     const int copies = EPI == EPI_PARTIAL ? g.ksplit : 1;
     kern<<<dim3((unsigned)(g.mtiles * g.ntiles * copies)), dim3(512), B8_LDS_IG, s>>>(g);
     YFS_CHECK_LAUNCH(name);
-    yfs_note_kernel("igemm8_kernel<%d,%d,epi%d%s>", 128 + FP1 * 32, 128 + FW1 * 64, EPI, M32 ? ",mfma32" : "");
+    yfs_note_kernel("igemm8_kernel<%d,%d,epi%d>", 128 + FP1 * 32, 128 + FW1 * 64, EPI);
     return YFS_OK;
 }
 
@@ -1006,9 +942,6 @@ int dispatch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
     }
     if constexpr (!SUB) {
         if (force == 8 && ok8) return launch_igemm8<EPI, 4>(g, s, name);
-        if constexpr (EPI == EPI_BIAS_LEAKY || EPI == EPI_MASK) {
-            if (force == 832 && ok8) return launch_igemm8<EPI, 4, 2, 1>(g, s, name);
-        }
         if (force == 87 && ok8) return launch_igemm8<EPI, 3>(g, s, name);
     }
     if (force == 256) return launch_igemm<256, 128, 4, 2, 3, EPI, SUB>(g, s, name);
