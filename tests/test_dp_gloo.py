@@ -61,6 +61,27 @@ def test_bucket_layout_skips_deferred_parameters():
             assert lo <= off and off + n <= hi
 
 
+def test_scale_ranges_cover_the_buckets_and_nothing_of_a_skipped_parameter():
+    """The 1/world factor is applied once per contiguous run of buckets (round 3: one launch per run instead of one per
+    bucket).  The runs must cover every bucket element exactly once, may take in the < 64 zero elements of alignment
+    padding between neighbours, and must not touch the slice of a parameter that has no bucket."""
+    offs, total = _layout()
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in SHAPES]
+    comm = dp.GradComm(world_size=2, bucket_bytes=64 * 1024)
+    skipped = params[4]
+    comm.attach(params, offs, torch.zeros(total), skip_ids={id(skipped)})
+    assert len(comm.buckets) >= 3 and len(comm._scale_ranges) == 2          # before and after the skipped weight
+    covered = np.zeros(total, int)
+    for lo, hi in comm._scale_ranges:
+        covered[lo:hi] += 1
+    assert covered.max() == 1
+    for lo, hi in comm.buckets:
+        assert (covered[lo:hi] == 1).all()
+    lo_s, n_s = offs[4]
+    assert (covered[lo_s:lo_s + n_s] == 0).all()
+    assert comm.exchange_streams == 0
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
