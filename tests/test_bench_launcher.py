@@ -63,3 +63,18 @@ def test_parent_fails_when_a_rank_fails_and_stops_the_others(tmp_path):
     """)
     assert r.returncode == 7
     assert "rank 1 exited with 7" in r.stderr
+
+
+def test_pmc_fields_come_from_the_committed_summaries():
+    """roofline.traffic / mfma_busy_pmc are read from the newest profiles/rNN summary (its "#json" line) and carry the
+    file's git blob hash, so that a number typed in by hand or a stale file shows in the record."""
+    vals, src = bench.committed_pmc("pmc_traffic_hbm_kernels.txt")
+    assert set(vals) == {"nms", "loss", "assign"} and all(v > 1e6 for v in vals.values())
+    assert src["file"].startswith("profiles/r") and len(src["git_blob"]) == 40
+    if os.path.isdir(os.path.join(ROOT, ".git")):
+        out = subprocess.run(["git", "hash-object", src["file"]], cwd=ROOT, capture_output=True, text=True)
+        if out.returncode == 0:
+            assert out.stdout.strip() == src["git_blob"]
+    kern, ksrc = bench.committed_pmc("conv_pmc_summary.txt")
+    assert any(k.startswith("igemm8_kernel") for k in kern) and all(0.0 < v["mfma_busy"] < 1.0 for v in kern.values())
+    assert bench.committed_pmc("no_such_summary.txt") == (None, None)
