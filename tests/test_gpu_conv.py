@@ -389,6 +389,8 @@ REAL_LAYERS = [  # name, n, cin, cout, k, hw, expected forward kernel, expected 
     ("feat.18", 32, 512, 1024, 3, 28, "igemm8_kernel<224,256,epi0>", "igemm8_kernel<224,256,epi1>", "wgrad8_kernel<256,256"),
     ("feat.2", 8, 192, 256, 3, 112, "igemm8_kernel<224,256,epi0>", "igemm8_kernel<256,192,epi1>", "wgrad8_kernel<192,256"),
     # feat.26 / feat.27 = Conv2D(1024, 1024, 3) at 7x7 (:253-254), full batch: 3136 pixels, K = 9216 -> split-K form
+    # feat.17 = Conv2D(512, 512, 1) at 28x28 (:240), full batch: the 1x1 layers with K >= 512 run on the 8-phase kernel too
+    ("feat.17", 64, 512, 512, 1, 28, "igemm8_kernel<224,256,epi0>", "igemm8_kernel<224,256,epi1>", "wgrad_kernel<128,128"),
     ("feat.26", 64, 1024, 1024, 3, 7, "igemm8_kernel<224,256,epi4,ksplit4>+splitk_epilogue<epi0>",
      "igemm8_kernel<224,256,epi4,ksplit4>+splitk_epilogue<epi1>", "wgrad8_kernel<256,256"),
 ]
