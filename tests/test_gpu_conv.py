@@ -472,3 +472,32 @@ def test_split_k_form_of_the_8phase_kernel_matches_the_unsplit_kernels(n, cin, c
                                      f"{float(r.flatten()[i])!r} at {i}")
         assert float((err > 0).float().mean()) < 0.02          # and the bulk is bit-identical
 
+
+
+def test_stride2_dgrad_at_the_real_feat25_shape_vs_torch_cpu():
+    """feat.25 = Conv2D(1024, 1024, 3, s=2) at 14x14 (:252), full batch: forward on the split-K 8-phase kernel, masked dgrad
+    as four parity classes on the 224 x 256 tile (one workgroup per CU), weight gradient on wgrad8_kernel - all as the
+    library dispatches them - against torch-CPU fp32 on the same bf16-rounded operands at 1e-2."""
+    from yolo_from_scratch_amd import _lib as L
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    n, c, hw = 64, 1024, 14
+    x, w, b = _case(n, c, c, 3, hw, seed=25)
+    x = x - 0.35
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    z_ref = F.conv2d(xr, wr, br, stride=2, padding=1)
+    dz = _bf(torch.randn(z_ref.shape, generator=torch.Generator().manual_seed(8)))
+    xg, wg, bg = torch.autograd.grad(z_ref, (xr, wr, br), dz)
+    xg = xg * torch.where(x > 0, 1.0, 0.1)
+    xd = co.nhwc(x.to(DEV), torch.bfloat16)
+    w16, wt16 = co.weight_prep(co.nhwc(w.to(DEV)))
+    y = co.conv_fwd(xd, w16, b.to(DEV), 2)
+    assert "epi4,ksplit" in L.last_kernel(), L.last_kernel()
+    _close(y, F.leaky_relu(z_ref, 0.1).detach(), "feat.25 forward")
+    dzd = co.nhwc(dz.to(DEV), torch.bfloat16)
+    dx = co.conv_dgrad(dzd, wt16, (hw, hw), 2, x_act=xd)
+    assert L.last_kernel() == "igemm_kernel<224,256,epi1,sub>", L.last_kernel()
+    _close(dx, xg, "feat.25 masked dgrad")
+    dw, db = co.conv_wgrad(xd, dzd, 3, 2)
+    assert L.last_kernel().startswith("wgrad8_kernel<256,256"), L.last_kernel()
+    _close(dw, wg, "feat.25 wgrad")
+    _close(db, bg, "feat.25 bias grad")
