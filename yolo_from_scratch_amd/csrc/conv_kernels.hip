@@ -109,6 +109,47 @@ __device__ __forceinline__ unsigned swz(int row, int chunk) { return (unsigned)(
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// ---- epilogue straight from the MFMA accumulators (igemm_kernel and igemm8_kernel, every form but the pool-fused one) ----
+// A lane of a 16x16 output fragment holds 4 consecutive channels of one pixel.  One v_permlane16_swap per register trades
+// them with the lane 16 further on (the next 4 channels of the same pixel) against that lane's values of a second
+// fragment: afterwards every lane owns 8 consecutive channels of one pixel, i.e. one 16 B store, 64 B runs per pixel row
+// and wave instruction.  x = the fragment that lanes with even lane>>4 keep, y = the one lanes with odd lane>>4 keep;
+// v[0..3] / v[4..7] = the lower / upper 4 channels of the lane's run.
+// The earlier form carried the fp32 tile through LDS (16 writes, a barrier, 8 read -> arithmetic -> store sweeps that the
+// row guard kept in separate basic blocks, twice per tile): ~11 K cycles per 224x256 tile whether 32 or 896 workgroups
+// were on the chip (tools/probes/igemm8_epilogue_alone.py), i.e. its own latency chain, not the memory system; this one
+// takes ~8 K (forward) and ~10.5 K instead of ~16.5 K (masked dgrad).  Same arithmetic per element (fma, compare,
+// multiply, one rounding): results are bit-identical.
+__device__ __forceinline__ void epi_swap8(const f32x4& x, const f32x4& y, float (&v)[8]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        // (scalar copies first: __builtin_bit_cast applied to x[r] itself reads element 0 for every r with this clang)
+        const float xr = x[r], yr = y[r];
+        const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, xr), __builtin_bit_cast(unsigned, yr), false, false);
+        v[r] = __builtin_bit_cast(float, (unsigned)sw[0]);
+        v[4 + r] = __builtin_bit_cast(float, (unsigned)sw[1]);
+    }
+}
+// 8 channels of one output pixel: o = element offset in out (and in act); av = act[o .. o+7], used by EPI_MASK only
+template <int EPI>
+__device__ __forceinline__ void epi_emit8(const IgemmArgs& g, long long o, float (&v)[8], const float (&sv)[8], const float (&bv)[8],
+                                          const bf16x8& av) {
+    if (EPI == EPI_BIAS_LEAKY) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float tv = __builtin_fmaf(v[j], sv[j], bv[j]);
+            v[j] = tv > 0.0f ? tv : tv * g.slope;
+        }
+    } else if (EPI == EPI_MASK) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)av[j] > 0.0f ? v[j] : v[j] * g.slope;
+    }
+    bf16x8 ov;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ov[j] = (bf16_t)v[j];
+    *reinterpret_cast<bf16x8*>(g.out + o) = ov;
+}
+
 // Epilogue row slabs: one pass when the fp32 tile (BM rows of BN*4+16 bytes) fits in ~72 KiB (the 128-wide tiles),
 // else the smallest power-of-two split whose slab fits inside the operand ring.
 template <int BM, int BN, int STAGES>
@@ -294,30 +335,75 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) igemm_kernel(IgemmArgs g) {
         cur = cur + 1 == STAGES ? 0 : cur + 1;
         nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
     }
+    // ---- epilogue ---------------------------------------------------------------------------------------------------
+    // acc[a][b][r] = out[pixel = wm*BM/WM + b*16 + (lane&15)][chan = wn*BN/WN + a*16 + (lane>>4)*4 + r]
+    if constexpr (EPI != EPI_POOL) {
+        // straight from the accumulators (see epi_swap8): channel fragments a, a + 1 pair up, lanes with odd fk take a + 1
+        static_assert(FC % 2 == 0, "the direct epilogue pairs channel fragments");
+        const int par = fk & 1, half = fk >> 1;
+        auto run = [&](auto guard_tag) {
+            // GUARD = the tile hangs over the end of the GEMM's rows: every row is tested.  Whole tiles run in one basic
+            // block; the masked form then sends all its activation loads first (one in flight per fragment pair, what the
+            // compiler schedules by itself, left the epilogue waiting on each)
+            constexpr bool GUARD = decltype(guard_tag)::value;
+            constexpr bool PRELOAD = EPI == EPI_MASK && !GUARD && FP * FC / 2 <= 16;
+            long long orow[FP];   // this lane's row of fragment b: element offset of its first channel in out, < 0 = no such row
+#pragma unroll
+            for (int b = 0; b < FP; ++b) {
+                int m = m0 + wm * (BM / WM) + b * 16 + frow;
+                const bool ok = !GUARD || m < Mc;
+                if (SUB && ok) {   // class-grid pixel -> pixel of the full output
+                    const int n = m / (OHc * OWc);
+                    const int rem = m - n * (OHc * OWc);
+                    const int oh = rem / OWc, ow = rem - oh * OWc;
+                    m = (n * g.OH + oh * g.sub_s + ph) * g.OW + ow * g.sub_s + pw;
+                }
+                orow[b] = ok ? (long long)m * g.NOUT : -1;
+            }
+            bf16x8 avs[FC / 2][FP];
+            if (PRELOAD) {
+#pragma unroll
+                for (int a2 = 0; a2 < FC / 2; ++a2)
+#pragma unroll
+                    for (int b = 0; b < FP; ++b)
+                        avs[a2][b] = *reinterpret_cast<const bf16x8*>(g.act + orow[b] + n0 + wn * (BN / WN) + a2 * 32 + par * 16 + half * 8);
+            }
+#pragma unroll
+            for (int a2 = 0; a2 < FC / 2; ++a2) {
+                const int c = n0 + wn * (BN / WN) + a2 * 32 + par * 16 + half * 8;
+                float bv[8], sv[8];
+                if (EPI == EPI_BIAS_LEAKY) {
+                    // per-channel scale of a folded BatchNorm: 1 when absent — fma(v, 1, b) == v + b bit for bit, so the
+                    // reference's bias-only block needs no second code path
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        bv[j] = g.bias[c + j];
+                        sv[j] = g.scale ? g.scale[c + j] : 1.0f;
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < FP; ++b) {
+                    float v[8];
+                    epi_swap8(acc[2 * a2][b], acc[2 * a2 + 1][b], v);
+                    if (GUARD && orow[b] < 0) continue;
+                    const long long o = orow[b] + c;
+                    bf16x8 av;
+                    if (EPI == EPI_MASK) av = PRELOAD ? avs[a2][b] : *reinterpret_cast<const bf16x8*>(g.act + o);
+                    epi_emit8<EPI>(g, o, v, sv, bv, av);
+                }
+            }
+        };
+        if (m0 + BM <= Mc) run(std::false_type()); else run(std::true_type());
+        return;
+    }
     __syncthreads();   // all waves done with the ring before the epilogue reuses it
 
-    // ---- epilogue: fp32 tile through LDS, then coalesced 16 B stores ---------------------------
-    // acc[a][b][r] = out[pixel = wm*BM/WM + b*16 + (lane&15)][chan = wn*BN/WN + a*16 + (lane>>4)*4 + r]
+    // ---- pool-fused epilogue: fp32 tile through LDS (a 2x2 window spans four pixel rows of the tile) -------------------
     // Large tiles go through the LDS in EPASS row slabs of PR rows so that the staging fits in the ring.
     constexpr int EPASS = igemm_epi_passes<BM, BN, STAGES>();
     constexpr int PR = BM / EPASS;
-    constexpr int TPR = BN / 8;            // threads per output row (8 channels each)
-    constexpr bool EVEN = NT % TPR == 0;   // false for the 192-wide tile (24 threads per row): generic item loop
-    constexpr int RPP = EVEN ? NT / TPR : 1;          // rows per sweep of the whole workgroup
-    constexpr int SWEEPS = EVEN ? PR / RPP : (PR * TPR + NT - 1) / NT;
-    static_assert(PR % 16 == 0 && (!EVEN || PR % RPP == 0), "epilogue slab must hold whole fragments and whole sweeps");
-    int ec = (tid % TPR) * 8;
-    const int er = tid / TPR;
-    // per-channel scale of a folded BatchNorm: 1 when absent — fma(v, 1, b) == v + b bit for bit, so the reference's
-    // bias-only block needs no second code path
-    float bv[8], sv[8];
-    if (EPI == EPI_BIAS_LEAKY && EVEN) {   // (EPI_POOL loads its bias per item below)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            bv[j] = g.bias[n0 + ec + j];
-            sv[j] = g.scale ? g.scale[n0 + ec + j] : 1.0f;
-        }
-    }
+    constexpr int TPR = BN / 8;            // items per window row (8 channels each)
+    static_assert(PR % 16 == 0, "epilogue slab must hold whole fragments");
 #pragma unroll
     for (int pass = 0; pass < EPASS; ++pass) {
 #pragma unroll
@@ -330,87 +416,42 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) igemm_kernel(IgemmArgs g) {
                 *reinterpret_cast<f32x4*>(smem + (prow - pass * PR + frow) * EPI_STRIDE + ch * 4) = acc[a][b];
             }
         __syncthreads();
-        if (EPI == EPI_POOL) {
-            // bias + LeakyReLU + one rounding to bf16 for the four pixels of a window, then the 2x2 max over the
-            // ROUNDED values with "first maximum wins" — bit-identical to conv forward followed by the pool kernel;
-            // only the pooled tensor and the 2-bit positions leave the CU (the full-resolution activation has no
-            // reader: pool backward works from the pooled output and the positions).
-            for (int item = tid; item < (PR / 4) * TPR; item += NT) {
-                const int w = item / TPR, c8 = item - w * TPR;
-                const int q = ((m0 + pass * PR) >> 2) + w;
-                if (q * 4 >= Mc) continue;
-                float bvp[8], svp[8];
+        // bias + LeakyReLU + one rounding to bf16 for the four pixels of a window, then the 2x2 max over the
+        // ROUNDED values with "first maximum wins" — bit-identical to conv forward followed by the pool kernel;
+        // only the pooled tensor and the 2-bit positions leave the CU (the full-resolution activation has no
+        // reader: pool backward works from the pooled output and the positions).
+        for (int item = tid; item < (PR / 4) * TPR; item += NT) {
+            const int w = item / TPR, c8 = item - w * TPR;
+            const int q = ((m0 + pass * PR) >> 2) + w;
+            if (q * 4 >= Mc) continue;
+            // per-channel scale of a folded BatchNorm: 1 when absent — fma(v, 1, b) == v + b bit for bit, so the
+            // reference's bias-only block needs no second code path
+            float bvp[8], svp[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                bvp[j] = g.bias[n0 + c8 * 8 + j];
+                svp[j] = g.scale ? g.scale[n0 + c8 * 8 + j] : 1.0f;
+            }
+            bf16x8 best;
+            unsigned packed = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned char* rp = smem + (4 * w + k) * EPI_STRIDE + c8 * 32;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(rp);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(rp + 16);
+                const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    bvp[j] = g.bias[n0 + c8 * 8 + j];
-                    svp[j] = g.scale ? g.scale[n0 + c8 * 8 + j] : 1.0f;
-                }
-                bf16x8 best;
-                unsigned packed = 0;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const unsigned char* rp = smem + (4 * w + k) * EPI_STRIDE + c8 * 32;
-                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(rp);
-                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(rp + 16);
-                    const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float t = __builtin_fmaf(v[j], svp[j], bvp[j]);
-                        const bf16_t yv = (bf16_t)(t > 0.0f ? t : t * g.slope);
-                        if (k == 0 || (float)yv > (float)best[j]) {
-                            best[j] = yv;
-                            packed = (packed & ~(3u << (2 * j))) | ((unsigned)k << (2 * j));
-                        }
-                    }
-                }
-                *reinterpret_cast<bf16x8*>(g.out + (long long)q * g.NOUT + n0 + c8 * 8) = best;
-                g.pool_idx[(long long)q * (g.NOUT / 8) + (n0 >> 3) + c8] = (unsigned short)packed;
-            }
-        } else {
-#pragma unroll
-        for (int p = 0; p < SWEEPS; ++p) {
-            int row = er + p * RPP;
-            if (!EVEN) {
-                const int item = tid + p * NT;
-                if (item >= PR * TPR) continue;
-                row = item / TPR;
-                ec = (item - row * TPR) * 8;
-                if (EPI == EPI_BIAS_LEAKY) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        bv[j] = g.bias[n0 + ec + j];
-                        sv[j] = g.scale ? g.scale[n0 + ec + j] : 1.0f;
+                    const float t = __builtin_fmaf(v[j], svp[j], bvp[j]);
+                    const bf16_t yv = (bf16_t)(t > 0.0f ? t : t * g.slope);
+                    if (k == 0 || (float)yv > (float)best[j]) {
+                        best[j] = yv;
+                        packed = (packed & ~(3u << (2 * j))) | ((unsigned)k << (2 * j));
                     }
                 }
             }
-            int m = m0 + pass * PR + row;
-            if (m >= Mc) continue;
-            if (SUB) {   // class-grid pixel -> pixel of the full output
-                const int n = m / (OHc * OWc);
-                const int rem = m - n * (OHc * OWc);
-                const int oh = rem / OWc, ow = rem - oh * OWc;
-                m = (n * g.OH + oh * g.sub_s + ph) * g.OW + ow * g.sub_s + pw;
-            }
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(smem + row * EPI_STRIDE + ec * 4);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(smem + row * EPI_STRIDE + ec * 4 + 16);
-            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            const long long o = (long long)m * g.NOUT + n0 + ec;
-            if (EPI == EPI_BIAS_LEAKY) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float t = __builtin_fmaf(v[j], sv[j], bv[j]);
-                    v[j] = t > 0.0f ? t : t * g.slope;
-                }
-            } else if (EPI == EPI_MASK) {
-                const bf16x8 av = *reinterpret_cast<const bf16x8*>(g.act + o);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = (float)av[j] > 0.0f ? v[j] : v[j] * g.slope;
-            }
-            bf16x8 ov;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) ov[j] = (bf16_t)v[j];
-            *reinterpret_cast<bf16x8*>(g.out + o) = ov;
-        }
+            *reinterpret_cast<bf16x8*>(g.out + (long long)q * g.NOUT + n0 + c8 * 8) = best;
+            g.pool_idx[(long long)q * (g.NOUT / 8) + (n0 >> 3) + c8] = (unsigned short)packed;
         }
         if (pass + 1 < EPASS) __syncthreads();
     }
@@ -488,7 +529,7 @@ __device__ long long yfs_ig8_dbg[8];
 // 64 rows, its MFMA blocks are half as long): feat.2's dgrad writes 192 channels.
 template <int EPI, int FP1, int FW1 = 2>
 __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
-    constexpr int BM = 128 + FP1 * 32, BN = 128 + FW1 * 64, NT = 512;
+    constexpr int BM = 128 + FP1 * 32, BN = 128 + FW1 * 64;
     IG8_T(0);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -694,52 +735,153 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
     if (wm == 0) bar();   // catch up with waves 4-7: every wave is past its last fragment read after this
     IG8_T(2);
 
-    // ---- epilogue: the fp32 tile through LDS in 64-row slabs, then coalesced 16 B stores (as igemm_kernel) ----
-    // acc[ph][wh][a][b][r] = out[pixel ph*128 + wm*NF*16 + b*16 + (lane&15)][chan wh*128 + wn*32 + a*16 + (lane>>4)*4 + r]
-    // with NF = 4 fragments per wave in the first pixel half and FP1 in the second; slab = one wave row of one half
-    constexpr int TPR = BN / 8, RPP = NT / TPR;          // (192 channels: 24 threads per row, 21 rows per sweep, 8 threads idle)
-    const int ec = (tid % TPR) * 8, er = tid / TPR;
-    const bool sweeper = tid < RPP * TPR;
-    float bv[8], sv[8];
-    if (EPI == EPI_BIAS_LEAKY) {
+    // ---- epilogue ---------------------------------------------------------------------------------------------------
+    // acc[ph][wh][a][b][r] = out[pixel ph*128 + wm*NF*16 + b*16 + (lane&15)][chan wh*128 + wn*NA*16 + a*16 + (lane>>4)*4 + r]
+    // with NF = 4 pixel fragments per wave in the first pixel half and FP1 in the second, NA = 2 channel fragments per
+    // wave in the first weight half and FW1 in the second.
+    if constexpr (EPI != EPI_POOL) {
+        // straight from the accumulators (see epi_swap8)
+        const int par = fk & 1, half = fk >> 1;
+        float bv[8], sv[8];
+        // GUARD = the tile hangs over the end of the GEMM's rows: every row is tested.  Whole tiles (all of them at this
+        // network's sizes) run without tests in one basic block, so the activation loads of the masked form and the stores
+        // of one fragment pair overlap the arithmetic of the next
+        auto run = [&](auto guard_tag) {
+        constexpr bool GUARD = decltype(guard_tag)::value;
+        // masked form, whole tile: all 16 (14) activation loads of the wave go out first; one load in flight per fragment
+        // pair (what the compiler schedules by itself) left the epilogue waiting ~700 cycles on each
+        constexpr bool PRELOAD = EPI == EPI_MASK && !GUARD;
+        bf16x8 avs[2][2][4];
+        if (PRELOAD) {
+#pragma unroll
+            for (int wh = 0; wh < 2; ++wh) {
+                const int NA = wh == 1 ? FW1 : 2;
+                const int c = n0 + wh * 128 + wn * (NA * 16) + (NA == 2 ? par * 16 : 0) + half * 8;
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph) {
+                    const int NF = ph == 1 ? FP1 : 4;
+                    const int r0 = m0 + ph * 128 + wm * (NF * 16) + frow;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        if (b >= NF || (NA == 1 && ((b & 1) || b + 1 >= NF))) continue;
+                        const int m = r0 + (NA == 2 ? b : b + par) * 16;
+                        avs[wh][ph][b] = *reinterpret_cast<const bf16x8*>(g.act + (long long)m * g.NOUT + c);
+                    }
+                }
+            }
+        }
+        auto emit = [&](int m, int c, float (&v)[8], const bf16x8& pre) {   // 8 channels from c of output row m
+            if (GUARD && m >= Mc) return;
+            const long long o = (long long)m * g.NOUT + c;
+            bf16x8 av;
+            if (EPI == EPI_MASK) av = PRELOAD ? pre : *reinterpret_cast<const bf16x8*>(g.act + o);
+            epi_emit8<EPI>(g, o, v, sv, bv, av);
+        };
+#pragma unroll
+        for (int wh = 0; wh < 2; ++wh) {
+            const int NA = wh == 1 ? FW1 : 2;
+            const int cbase = n0 + wh * 128 + wn * (NA * 16);
+            // after the swap: NA == 2 pairs the two channel fragments of one pixel fragment (lanes with odd fk own fragment
+            // a = 1); NA == 1 pairs pixel fragments b, b + 1 of the only channel fragment (lanes with odd fk own rows of b + 1)
+            const int c = cbase + (NA == 2 ? par * 16 : 0) + half * 8;
+            if (EPI == EPI_BIAS_LEAKY) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    bv[j] = g.bias[c + j];
+                    sv[j] = g.scale ? g.scale[c + j] : 1.0f;
+                }
+            }
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                const int NF = ph == 1 ? FP1 : 4;
+                const int r0 = m0 + ph * 128 + wm * (NF * 16) + frow;
+                if (EPI == EPI_PARTIAL) {   // the raw fp32 sums of this block's K range; the epilogue runs in the reduction
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            if (a >= NA || b >= NF) continue;
+                            const int m = r0 + b * 16;
+                            if (!GUARD || m < Mc)
+                                *reinterpret_cast<f32x4*>(g.partial + ((long long)split * Mc + m) * g.NOUT + cbase + a * 16 + fk * 4) =
+                                    acc[ph][wh][a][b];
+                        }
+                } else if (NA == 2) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        if (b >= NF) continue;
+                        float v[8];
+                        epi_swap8(acc[ph][wh][0][b], acc[ph][wh][1][b], v);
+                        emit(r0 + b * 16, c, v, avs[wh][ph][b]);
+                    }
+                } else {
+#pragma unroll
+                    for (int b = 0; b + 1 < NF; b += 2) {
+                        float v[8];
+                        epi_swap8(acc[ph][wh][0][b], acc[ph][wh][0][b + 1], v);
+                        emit(r0 + (b + par) * 16, c, v, avs[wh][ph][b]);
+                    }
+                    if (NF & 1) {   // (224 x 192 tile: a third pixel fragment without a partner leaves as 8 B per lane)
+                        const int m = r0 + (NF - 1) * 16, c4 = cbase + fk * 4;
+                        if (!GUARD || m < Mc) {
+                            const long long o = (long long)m * g.NOUT + c4;
+                            f32x4 v = acc[ph][wh][0][NF - 1];
+                            if (EPI == EPI_BIAS_LEAKY) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    const float tv = __builtin_fmaf(v[j], g.scale ? g.scale[c4 + j] : 1.0f, g.bias[c4 + j]);
+                                    v[j] = tv > 0.0f ? tv : tv * g.slope;
+                                }
+                            } else if (EPI == EPI_MASK) {
+                                const bf16x4 av = *reinterpret_cast<const bf16x4*>(g.act + o);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v[j] = (float)av[j] > 0.0f ? v[j] : v[j] * g.slope;
+                            }
+                            bf16x4 ov;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) ov[j] = (bf16_t)v[j];
+                            *reinterpret_cast<bf16x4*>(g.out + o) = ov;
+                        }
+                    }
+                }
+            }
+        }
+        };
+        if (m0 + BM <= Mc) run(std::false_type()); else run(std::true_type());
+    } else {
+        // EPI_POOL: the fp32 tile through LDS (the 2x2 windows span four pixel rows of the tile = four lanes of a fragment
+        // column, and the window's argmax goes out beside the maximum).  Two passes (pixel halves); in each, both wave rows
+        // park their slab (<= 64 rows of the fp32 tile) side by side in LDS (2 x 65 KiB: the ring and the staging state
+        // behind it are dead by now), one barrier, then one item per thread and slab: (window, 8 channels); see
+        // igemm_kernel for the pooling rule
+        constexpr int TPR = BN / 8;
+        constexpr int SLAB = 64 * B8_EPI_STRIDE;
+        static_assert(2 * SLAB <= B8_LDS_IG, "epilogue slabs must fit in the kernel's LDS");
+        const int w = tid / TPR, c8 = tid - w * TPR;
+        float bvp[8], svp[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            bv[j] = g.bias[n0 + ec + j];
-            sv[j] = g.scale ? g.scale[n0 + ec + j] : 1.0f;
+            bvp[j] = g.bias[n0 + c8 * 8 + j];
+            svp[j] = g.scale ? g.scale[n0 + c8 * 8 + j] : 1.0f;
         }
-    }
-    // two passes (pixel halves); in each, both wave rows park their slab (<= 64 rows of the fp32 tile) side by side in
-    // LDS (2 x 65 KiB: the ring and the staging state behind it are dead by now), one barrier, then every thread carries
-    // rows of both slabs out: 3 barriers per tile where the four-slab version of this epilogue had 7
-    constexpr int SLAB = 64 * B8_EPI_STRIDE;
-    static_assert(2 * SLAB <= B8_LDS_IG, "epilogue slabs must fit in the kernel's LDS");
 #pragma unroll
-    for (int ph = 0; ph < 2; ++ph) {
-        constexpr int kNF[2] = {4, FP1};
-        const int NF = kNF[ph];
-        const int PR = NF * 16;                                       // rows per slab
-        const int rbase = ph * 128;                                   // first tile row of slab 0; slab 1 follows at + PR
-        unsigned char* const myslab = smem + wm * SLAB;
+        for (int ph = 0; ph < 2; ++ph) {
+            constexpr int kNF[2] = {4, FP1};
+            const int NF = kNF[ph];
+            const int PR = NF * 16;                                       // rows per slab
+            const int rbase = ph * 128;                                   // first tile row of slab 0; slab 1 follows at + PR
+            unsigned char* const myslab = smem + wm * SLAB;
 #pragma unroll
-        for (int wh = 0; wh < 2; ++wh)
+            for (int wh = 0; wh < 2; ++wh)
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+                for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    if (b >= NF || (wh == 1 && a >= FW1)) continue;
-                    const int ch = wh * 128 + wn * (wh == 1 ? FW1 * 16 : 32) + a * 16 + fk * 4;
-                    *reinterpret_cast<f32x4*>(myslab + (b * 16 + frow) * B8_EPI_STRIDE + ch * 4) = acc[ph][wh][a][b];
-                }
-        __syncthreads();
-        if (EPI == EPI_POOL) {
-            // one item per thread and slab: (window, 8 channels); see igemm_kernel for the pooling rule
-            const int w = tid / TPR, c8 = tid - w * TPR;
-            float bvp[8], svp[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                bvp[j] = g.bias[n0 + c8 * 8 + j];
-                svp[j] = g.scale ? g.scale[n0 + c8 * 8 + j] : 1.0f;
-            }
+                    for (int b = 0; b < 4; ++b) {
+                        if (b >= NF || (wh == 1 && a >= FW1)) continue;
+                        const int ch = wh * 128 + wn * (wh == 1 ? FW1 * 16 : 32) + a * 16 + fk * 4;
+                        *reinterpret_cast<f32x4*>(myslab + (b * 16 + frow) * B8_EPI_STRIDE + ch * 4) = acc[ph][wh][a][b];
+                    }
+            __syncthreads();
 #pragma unroll
             for (int sl = 0; sl < 2; ++sl) {
                 const int q = ((m0 + rbase + sl * PR) >> 2) + w;
@@ -766,43 +908,8 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
                     g.pool_idx[(long long)q * (g.NOUT / 8) + (n0 >> 3) + c8] = (unsigned short)packed;
                 }
             }
-        } else {
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const int rr = er + p * RPP;                          // row of the two stacked slabs
-                if (rr >= 2 * PR || !sweeper) continue;
-                const int sl = rr >= PR ? 1 : 0, row = rr - sl * PR;
-                const int m = m0 + rbase + rr;
-                if (m >= Mc) continue;
-                const unsigned char* rp = smem + sl * SLAB + row * B8_EPI_STRIDE + ec * 4;
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(rp);
-                const f32x4 v1 = *reinterpret_cast<const f32x4*>(rp + 16);
-                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                const long long o = (long long)m * g.NOUT + n0 + ec;
-                if (EPI == EPI_PARTIAL) {   // the raw fp32 sums of this block's K range; the epilogue runs in the reduction
-                    float* dst = g.partial + (long long)split * Mc * g.NOUT + o;
-                    *reinterpret_cast<f32x4*>(dst) = v0;
-                    *reinterpret_cast<f32x4*>(dst + 4) = v1;
-                    continue;
-                }
-                if (EPI == EPI_BIAS_LEAKY) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float tv = __builtin_fmaf(v[j], sv[j], bv[j]);
-                        v[j] = tv > 0.0f ? tv : tv * g.slope;
-                    }
-                } else if (EPI == EPI_MASK) {
-                    const bf16x8 av = *reinterpret_cast<const bf16x8*>(g.act + o);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = (float)av[j] > 0.0f ? v[j] : v[j] * g.slope;
-                }
-                bf16x8 ov;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) ov[j] = (bf16_t)v[j];
-                *reinterpret_cast<bf16x8*>(g.out + o) = ov;
-            }
+            if (ph == 0) __syncthreads();
         }
-        if (ph == 0) __syncthreads();
     }
     IG8_T(3);
 #ifdef YFS_IG8_TIMING
