@@ -553,34 +553,6 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
     // what pushed the two-phase K-step over 256 VGPRs.  st[j] = byte offset of row j's tap-(0,0) source pixel,
     // st[4 + j] = (bh << 16) | (bw & 0xFFFF), that pixel's row / column (both within +-16 K: dispatch_igemm checks)
     unsigned* const st = reinterpret_cast<unsigned*>(smem + B8_LDS) + tid * 8;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {   // j = half * 2 + i: tile row half*128 + wave*16 + i*8 + (lane >> 3)
-        const int hr = wave * 16 + (j & 1) * 8 + (lane >> 3);   // row inside the half-tile
-        const int m = m0 + (j >> 1) * 128 + hr;
-        if (m < Mc && (j < 2 || hr < FP1 * 32)) {
-            int n, oh, ow;
-            // (host-prepared multipliers: four rows x two divisions per thread were ~280 instructions of every tile's prologue)
-            if (EPI == EPI_POOL) {   // window-major row order (see igemm_kernel); div_hw / div_w divide by the pooled grid
-                const int q = m >> 2, sub = m & 3;
-                n = (int)fdiv((unsigned)q, g.div_hw);
-                const int r = q - n * (int)g.div_hw.d;
-                const int py = (int)fdiv((unsigned)r, g.div_w), px = r - py * (int)g.div_w.d;
-                oh = 2 * py + (sub >> 1);
-                ow = 2 * px + (sub & 1);
-            } else {
-                n = (int)fdiv((unsigned)m, g.div_hw);
-                const int rem = m - n * (int)g.div_hw.d;
-                oh = (int)fdiv((unsigned)rem, g.div_w);
-                ow = rem - oh * (int)g.div_w.d;
-            }
-            const int bh = oh * g.s_mul - g.pad, bw = ow * g.s_mul - g.pad;
-            st[4 + j] = ((unsigned)bh << 16) | ((unsigned)bw & 0xFFFFu);
-            st[j] = (unsigned)(((long long)(n * g.H + bh) * g.W + bw) * g.PS * 2) + chunk * 16;
-        } else {
-            st[4 + j] = 0xC000C000u;   // (-16384, -16384): outside for every tap
-            st[j] = 0;
-        }
-    }
     const unsigned ktot = (unsigned)(g.KH * g.KW * g.C);
     const unsigned wrow = (unsigned)(n0 + wave * 16 + (lane >> 3)) * ktot * 2 + chunk * 16;
     const int cchunks = g.C / BK;
@@ -678,9 +650,39 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    // prologue: tile 0 complete, W0 / P0 / W1 of tile 1 in flight (the steady state at the top of a K-step)
+    // prologue: tile 0 complete, W0 / P0 / W1 of tile 1 in flight (the steady state at the top of a K-step).  The weight
+    // half-tiles of tile 0 need no pixel coordinates: they are on their way while those are computed
+    stage_W(0, 0); stage_W(1, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {   // j = half * 2 + i: tile row half*128 + wave*16 + i*8 + (lane >> 3)
+        const int hr = wave * 16 + (j & 1) * 8 + (lane >> 3);   // row inside the half-tile
+        const int m = m0 + (j >> 1) * 128 + hr;
+        if (m < Mc && (j < 2 || hr < FP1 * 32)) {
+            int n, oh, ow;
+            // (host-prepared multipliers: four rows x two divisions per thread were ~280 instructions of every tile's prologue)
+            if (EPI == EPI_POOL) {   // window-major row order (see igemm_kernel); div_hw / div_w divide by the pooled grid
+                const int q = m >> 2, sub = m & 3;
+                n = (int)fdiv((unsigned)q, g.div_hw);
+                const int r = q - n * (int)g.div_hw.d;
+                const int py = (int)fdiv((unsigned)r, g.div_w), px = r - py * (int)g.div_w.d;
+                oh = 2 * py + (sub >> 1);
+                ow = 2 * px + (sub & 1);
+            } else {
+                n = (int)fdiv((unsigned)m, g.div_hw);
+                const int rem = m - n * (int)g.div_hw.d;
+                oh = (int)fdiv((unsigned)rem, g.div_w);
+                ow = rem - oh * (int)g.div_w.d;
+            }
+            const int bh = oh * g.s_mul - g.pad, bw = ow * g.s_mul - g.pad;
+            st[4 + j] = ((unsigned)bh << 16) | ((unsigned)bw & 0xFFFFu);
+            st[j] = (unsigned)(((long long)(n * g.H + bh) * g.W + bw) * g.PS * 2) + chunk * 16;
+        } else {
+            st[4 + j] = 0xC000C000u;   // (-16384, -16384): outside for every tap
+            st[j] = 0;
+        }
+    }
     tap_offsets();
-    stage_W(0, 0); stage_P(0, 0); stage_W(1, 0); stage_P(1, 0);
+    stage_P(0, 0); stage_P(1, 0);
     if (nit > 1) {
         advance();
         stage_W(0, 1); stage_P(0, 1); stage_W(1, 1);
