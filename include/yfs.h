@@ -176,6 +176,14 @@ int yfs_conv2d_fwd_ws_bf16(const void *x, const void *w, const float *scale, con
 int yfs_conv2d_dgrad_ws_bf16(const void *dz, const void *wt, const void *x_act, void *dx, int64_t N, int H, int W,
                              int Cin, int Cout, int K, int stride, float slope, void *workspace, size_t workspace_bytes,
                              void *stream);
+/* yfs_conv2d_dgrad_bf16 with x_act = y_pooled, then yfs_maxpool2_bwd_idx_bf16, in one launch: the autograd of a
+ * Conv2D block whose input is a pool() output (:221-222, :224-225, :231-232, :245-246 read backwards), carried through
+ * that pool.  H, W = the block's input grid = the pool's OUTPUT grid; y_pooled [N,H,W,Cin] bf16 (LeakyReLU derivative of
+ * the routed element), pool_idx = the pool's record (layout of yfs_maxpool2_fwd_idx_bf16); dx_full [N,2H,2W,Cin] bf16 is
+ * the gradient of the pool's INPUT: the masked value at the recorded window position, zeros at the other three.
+ * Stride 1 only.  Bit-identical to the two calls it replaces; the pooled-resolution gradient is never written. */
+int yfs_conv2d_dgrad_unpool_bf16(const void *dz, const void *wt, const void *y_pooled, const void *pool_idx, void *dx_full,
+                                 int64_t N, int H, int W, int Cin, int Cout, int K, float slope, void *stream);
 /* dw [Cout,K,K,Cin] fp32 (+)= sum_pixels dz (x) x ; db [Cout] fp32 (+)= sum_pixels dz.
  * accumulate != 0 adds into dw/db (gradient accumulation), else overwrites. */
 size_t yfs_conv2d_wgrad_workspace_bytes(int64_t N, int H, int W, int Cin, int Cout, int K, int stride);

@@ -501,3 +501,25 @@ def test_stride2_dgrad_at_the_real_feat25_shape_vs_torch_cpu():
     assert L.last_kernel().startswith("wgrad8_kernel<256,256"), L.last_kernel()
     _close(dw, wg, "feat.25 wgrad")
     _close(db, bg, "feat.25 bias grad")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,cin,cout,k,hw", [(2, 64, 128, 1, 7), (3, 128, 64, 1, 10), (1, 192, 128, 3, 9), (2, 256, 128, 1, 13),
+                                             (5, 128, 256, 3, 6), (64, 256, 128, 1, 56)])
+def test_dgrad_carried_through_the_pool_in_front_is_bit_identical(n, cin, cout, k, hw):
+    """yfs_conv2d_dgrad_unpool_bf16 (the dgrad of a block behind a 2x2 pool, writing that pool's INPUT gradient) against
+    the two launches it replaces: masked dgrad at the pooled resolution, then yfs_maxpool2_bwd_idx_bf16.  Ragged pixel
+    counts, 64 / 128 / 192 / 256 output channels (every tile of the small kernel), 1x1 and 3x3, and feat.4's real shape
+    (batch 64, 256 channels at 56x56 -> 112x112).  The record comes from the pool's own forward."""
+    from yolo_from_scratch_amd import model as ym
+    g = torch.Generator().manual_seed(n * 1000 + cin + hw)
+    x_full = co.nhwc(torch.randn(n, cin, 2 * hw, 2 * hw, generator=g).to(DEV), torch.bfloat16)
+    y_pooled, idx = ym._pool_fwd_idx(x_full)
+    dz = co.nhwc(torch.randn(n, cout, hw, hw, generator=g).to(DEV), torch.bfloat16)
+    w = co.nhwc(((torch.rand(cout, cin, k, k, generator=g) * 2 - 1) / (cin * k * k) ** 0.5).to(DEV))
+    wt16 = co.weight_prep(w)[1]
+    ref = ym._pool_bwd_idx(y_pooled, idx, co.conv_dgrad(dz, wt16, (hw, hw), 1, x_act=y_pooled), fuse_leaky=False)
+    got = co.conv_dgrad_unpool(dz, wt16, y_pooled, idx)
+    assert got.shape == ref.shape == (n, cin, 2 * hw, 2 * hw)
+    assert torch.equal(got, ref)
+    assert float((got != 0).float().mean()) < 0.2501      # one position per window

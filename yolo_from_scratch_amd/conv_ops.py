@@ -203,6 +203,28 @@ def conv_dgrad(dz, wt16, in_hw, stride=1, x_act=None, slope=0.1):
     return dx
 
 
+def conv_dgrad_unpool(dz, wt16, y_pooled, pool_idx, slope=0.1):
+    """Input gradient of a stride-1 block whose input is the output of a 2x2 max pool, carried through that pool in the
+    same launch: returns the gradient of the pool's INPUT [N, Cin, 2H, 2W] (the LeakyReLU-masked dgrad value at the
+    window position ``pool_idx`` recorded, zeros at the other three).  Bit-identical to
+    ``conv_dgrad(..., x_act=y_pooled)`` followed by the pool backward; the pooled-resolution gradient is never written."""
+    L.require_cuda(dz, wt16, y_pooled, pool_idx)
+    dz = nhwc(dz, torch.bfloat16)
+    y_pooled = nhwc(y_pooled, torch.bfloat16)
+    n, cout = dz.shape[0], dz.shape[1]
+    cin, cout2, k, _ = wt16.shape
+    h, w = y_pooled.shape[2:]
+    if cout2 != cout or tuple(dz.shape[2:]) != (h, w) or y_pooled.shape[1] != cin or y_pooled.shape[0] != n:
+        raise L.YfsError(f"conv_dgrad_unpool: dz {tuple(dz.shape)} / y_pooled {tuple(y_pooled.shape)} do not match the weight")
+    if pool_idx.dtype != torch.int16 or pool_idx.numel() != n * h * w * (cin // 8):
+        raise L.YfsError("conv_dgrad_unpool: pool_idx must be the int16 record of the pool that produced y_pooled")
+    dx = _empty_nhwc(n, cin, 2 * h, 2 * w, dz.device)
+    L.check(L.lib().yfs_conv2d_dgrad_unpool_bf16(L.ptr(dz), L.ptr(wt16), L.ptr(y_pooled), L.ptr(pool_idx), L.ptr(dx), L.i64(n),
+                                                 L.c_int(h), L.c_int(w), L.c_int(cin), L.c_int(cout), L.c_int(k),
+                                                 L.c_float(slope), L.stream()), "yfs_conv2d_dgrad_unpool_bf16")
+    return dx
+
+
 def conv_wgrad(x, dz, k, stride=1, dw=None, db=None, want_db=True, accumulate=None):
     """dw fp32 (logical [Cout,Cin,K,K] channels_last), db fp32 [Cout].  When dw/db are given the result is
     written into them: added when ``accumulate`` (default for given buffers), else overwritten."""

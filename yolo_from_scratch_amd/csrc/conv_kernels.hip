@@ -46,7 +46,7 @@ __device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned o
 constexpr int kThreads = 256;
 constexpr int BK = 64;   // reduction depth per LDS tile (128 B rows)
 
-enum { EPI_BIAS_LEAKY = 0, EPI_MASK = 1, EPI_NONE = 2, EPI_POOL = 3, EPI_PARTIAL = 4 };
+enum { EPI_BIAS_LEAKY = 0, EPI_MASK = 1, EPI_NONE = 2, EPI_POOL = 3, EPI_PARTIAL = 4, EPI_UNPOOL = 5 };
 
 // n / d for 0 <= n < 2^31 with a host-prepared multiplier (Granlund-Montgomery round-up form).
 struct FastDiv {
@@ -70,6 +70,8 @@ struct IgemmArgs {
     const float* scale;   // [NOUT] or null    (folded BatchNorm: y = leaky(acc * scale + bias); null = 1, the reference's block)
     const bf16_t* act;    // [M][NOUT]         (EPI_MASK: multiply by act > 0 ? 1 : slope)
     unsigned short* pool_idx;   // EPI_POOL: [M/4][NOUT/8] eight 2-bit window positions each; out is then [M/4][NOUT]
+                                // EPI_UNPOOL (read): [M][NOUT/8], the record of the 2x2 pool whose OUTPUT the rows are; out is then
+                                // [N][2*OH][2*OW][NOUT]: EPI_MASK's value at the recorded position of each window, zeros elsewhere
     bf16_t* out;          // [M][NOUT]
     int N, H, W, C;
     int OH, OW, NOUT;
@@ -130,24 +132,68 @@ __device__ __forceinline__ void epi_swap8(const f32x4& x, const f32x4& y, float 
         v[4 + r] = __builtin_bit_cast(float, (unsigned)sw[1]);
     }
 }
-// 8 channels of one output pixel: o = element offset in out (and in act); av = act[o .. o+7], used by EPI_MASK only
+// 8 channels of one output pixel after the layer's epilogue arithmetic, rounded once; av = the activation the derivative
+// mask is taken from (EPI_MASK, EPI_UNPOOL only)
 template <int EPI>
-__device__ __forceinline__ void epi_emit8(const IgemmArgs& g, long long o, float (&v)[8], const float (&sv)[8], const float (&bv)[8],
-                                          const bf16x8& av) {
+__device__ __forceinline__ bf16x8 epi_value8(const IgemmArgs& g, float (&v)[8], const float (&sv)[8], const float (&bv)[8],
+                                             const bf16x8& av) {
     if (EPI == EPI_BIAS_LEAKY) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float tv = __builtin_fmaf(v[j], sv[j], bv[j]);
             v[j] = tv > 0.0f ? tv : tv * g.slope;
         }
-    } else if (EPI == EPI_MASK) {
+    } else if (EPI == EPI_MASK || EPI == EPI_UNPOOL) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (float)av[j] > 0.0f ? v[j] : v[j] * g.slope;
     }
     bf16x8 ov;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ov[j] = (bf16_t)v[j];
-    *reinterpret_cast<bf16x8*>(g.out + o) = ov;
+    return ov;
+}
+// o = element offset of the 8 channels in out (and in act)
+template <int EPI>
+__device__ __forceinline__ void epi_emit8(const IgemmArgs& g, long long o, float (&v)[8], const float (&sv)[8], const float (&bv)[8],
+                                          const bf16x8& av) {
+    *reinterpret_cast<bf16x8*>(g.out + o) = epi_value8<EPI>(g, v, sv, bv, av);
+}
+// EPI_UNPOOL = EPI_MASK + the backward of the 2x2 max pool in front of the layer (a dgrad whose input is a pool's output):
+// the masked value goes to the window position the pool recorded, zeros to the other three (r[k]: k = dy * 2 + dx).
+// Bit-identical to EPI_MASK followed by maxpool2_bwd_idx_kernel.
+__device__ __forceinline__ void epi_route4(const bf16x8& gv, unsigned packed, bf16x8 (&r)[4]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const unsigned bi = (packed >> (2 * j)) & 3u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k][j] = (unsigned)k == bi ? gv[j] : (bf16_t)0.0f;
+    }
+}
+// every lane gets the value of the lane 8 further on in its group of 16 (wrapping): DPP row_ror:8
+__device__ __forceinline__ unsigned epi_ror8(unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xF, 0xF, false); }
+__device__ __forceinline__ long long epi_ror8(long long x) {
+    const unsigned lo = epi_ror8((unsigned)x), hi = epi_ror8((unsigned)((unsigned long long)x >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ bf16x8 epi_ror8(const bf16x8& x) {
+    const u32x4 in = __builtin_bit_cast(u32x4, x);
+    u32x4 out;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned t = in[i];
+        out[i] = epi_ror8(t);
+    }
+    return __builtin_bit_cast(bf16x8, out);
+}
+__device__ __forceinline__ bf16x8 epi_sel(bool c, const bf16x8& a, const bf16x8& b) {
+    const u32x4 ua = __builtin_bit_cast(u32x4, a), ub = __builtin_bit_cast(u32x4, b);
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned x = ua[i], y = ub[i];
+        o[i] = c ? x : y;
+    }
+    return __builtin_bit_cast(bf16x8, o);
 }
 
 // Epilogue row slabs: one pass when the fp32 tile (BM rows of BN*4+16 bytes) fits in ~72 KiB (the 128-wide tiles),
@@ -346,12 +392,21 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) igemm_kernel(IgemmArgs g) {
             // block; the masked form then sends all its activation loads first (one in flight per fragment pair, what the
             // compiler schedules by itself, left the epilogue waiting on each)
             constexpr bool GUARD = decltype(guard_tag)::value;
-            constexpr bool PRELOAD = EPI == EPI_MASK && !GUARD && FP * FC / 2 <= 16;
+            constexpr bool MASKED = EPI == EPI_MASK || EPI == EPI_UNPOOL;
+            constexpr bool PRELOAD = MASKED && !GUARD && FP * FC / 2 <= 16;
             long long orow[FP];   // this lane's row of fragment b: element offset of its first channel in out, < 0 = no such row
+            long long o00[EPI == EPI_UNPOOL ? FP : 1];   // EPI_UNPOOL: ... of the row's 2x2 window in the full-resolution out
 #pragma unroll
             for (int b = 0; b < FP; ++b) {
                 int m = m0 + wm * (BM / WM) + b * 16 + frow;
                 const bool ok = !GUARD || m < Mc;
+                if (EPI == EPI_UNPOOL) {
+                    const int mm = ok ? m : 0;
+                    const int n = mm / (g.OH * g.OW);
+                    const int rem = mm - n * (g.OH * g.OW);
+                    const int oh = rem / g.OW, ow = rem - oh * g.OW;
+                    o00[b] = ((long long)(n * 2 * g.OH + 2 * oh) * (2 * g.OW) + 2 * ow) * g.NOUT;
+                }
                 if (SUB && ok) {   // class-grid pixel -> pixel of the full output
                     const int n = m / (OHc * OWc);
                     const int rem = m - n * (OHc * OWc);
@@ -361,13 +416,88 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) igemm_kernel(IgemmArgs g) {
                 orow[b] = ok ? (long long)m * g.NOUT : -1;
             }
             bf16x8 avs[FC / 2][FP];
+            unsigned short pks[FC / 2][FP];
             if (PRELOAD) {
 #pragma unroll
                 for (int a2 = 0; a2 < FC / 2; ++a2)
 #pragma unroll
-                    for (int b = 0; b < FP; ++b)
-                        avs[a2][b] = *reinterpret_cast<const bf16x8*>(g.act + orow[b] + n0 + wn * (BN / WN) + a2 * 32 + par * 16 + half * 8);
+                    for (int b = 0; b < FP; ++b) {
+                        const long long o = orow[b] + n0 + wn * (BN / WN) + a2 * 32 + par * 16 + half * 8;
+                        avs[a2][b] = *reinterpret_cast<const bf16x8*>(g.act + o);
+                        if (EPI == EPI_UNPOOL) pks[a2][b] = g.pool_idx[o >> 3];
+                    }
             }
+            const long long down = (long long)(2 * g.OW) * g.NOUT;   // EPI_UNPOOL: one full-resolution row further down
+            if constexpr (FC % 4 == 0 && EPI == EPI_UNPOOL) {
+                // 128 B runs: two fragment pairs (64 channels) per step.  After the swap a store instruction would cover 16
+                // rows x 64 B; lanes of rows 0-7 trade their upper 32 channels for the lower 32 of rows 8-15 (DPP
+                // row_ror:8), so that one instruction writes rows 0-7 and the next rows 8-15, 128 B = whole L2 lines each.
+                // Only this store-bound form (four output pixels per GEMM row) gains from it: feat.4 169 -> 128 us, feat.9
+                // 98 -> 79; the ordinary forward / dgrad epilogues of the 1x1 layers measured 0-1 % slower with it (same
+                // box, L4 / L6 / L9 / L17 / L20: 627-635 -> 636-637 us) and keep the 64 B runs.
+                const bool lo8 = frow < 8;
+                long long prow[FP], p00[EPI == EPI_UNPOOL ? FP : 1];   // the partner lane's rows
+#pragma unroll
+                for (int b = 0; b < FP; ++b) {
+                    prow[b] = epi_ror8(orow[b]);
+                    if (EPI == EPI_UNPOOL) p00[b] = epi_ror8(o00[b]);
+                }
+#pragma unroll
+                for (int a4 = 0; a4 < FC / 4; ++a4) {
+                    const int cA = n0 + wn * (BN / WN) + a4 * 64 + par * 16 + half * 8, cB = cA + 32;
+                    float bvA[8], svA[8], bvB[8], svB[8];
+                    if (EPI == EPI_BIAS_LEAKY) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            bvA[j] = g.bias[cA + j];
+                            svA[j] = g.scale ? g.scale[cA + j] : 1.0f;
+                            bvB[j] = g.bias[cB + j];
+                            svB[j] = g.scale ? g.scale[cB + j] : 1.0f;
+                        }
+                    }
+#pragma unroll
+                    for (int b = 0; b < FP; ++b) {
+                        float vA[8], vB[8];
+                        epi_swap8(acc[4 * a4][b], acc[4 * a4 + 1][b], vA);
+                        epi_swap8(acc[4 * a4 + 2][b], acc[4 * a4 + 3][b], vB);
+                        const bool own = !GUARD || orow[b] >= 0, partner = !GUARD || prow[b] >= 0;
+                        bf16x8 avA = {}, avB = {};
+                        unsigned pkA = 0, pkB = 0;
+                        if (MASKED) {
+                            if (PRELOAD) {
+                                avA = avs[2 * a4][b];
+                                avB = avs[2 * a4 + 1][b];
+                                if (EPI == EPI_UNPOOL) { pkA = pks[2 * a4][b]; pkB = pks[2 * a4 + 1][b]; }
+                            } else if (own) {
+                                avA = *reinterpret_cast<const bf16x8*>(g.act + orow[b] + cA);
+                                avB = *reinterpret_cast<const bf16x8*>(g.act + orow[b] + cB);
+                                if (EPI == EPI_UNPOOL) { pkA = g.pool_idx[(orow[b] + cA) >> 3]; pkB = g.pool_idx[(orow[b] + cB) >> 3]; }
+                            }
+                        }
+                        const bf16x8 ovA = epi_value8<EPI>(g, vA, svA, bvA, avA), ovB = epi_value8<EPI>(g, vB, svB, bvB, avB);
+                        // first store: rows 0-7 (their own lanes at cA, the partners at cB); second store: rows 8-15
+                        const bool st1 = lo8 ? own : partner, st2 = lo8 ? partner : own;
+                        if constexpr (EPI == EPI_UNPOOL) {
+                            bf16x8 rA[4], rB[4];
+                            epi_route4(ovA, pkA, rA);
+                            epi_route4(ovB, pkB, rB);
+                            const long long o1 = lo8 ? o00[b] + cA : p00[b] + cB, o2 = lo8 ? p00[b] + cA : o00[b] + cB;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const bf16x8 recv = epi_ror8(epi_sel(lo8, rB[k], rA[k]));
+                                const long long ok = (k & 1) * g.NOUT + (k >> 1) * down;
+                                if (st1) *reinterpret_cast<bf16x8*>(g.out + o1 + ok) = epi_sel(lo8, rA[k], recv);
+                                if (st2) *reinterpret_cast<bf16x8*>(g.out + o2 + ok) = epi_sel(lo8, recv, rB[k]);
+                            }
+                        } else {
+                            const bf16x8 recv = epi_ror8(epi_sel(lo8, ovB, ovA));
+                            const long long o1 = lo8 ? orow[b] + cA : prow[b] + cB, o2 = lo8 ? prow[b] + cA : orow[b] + cB;
+                            if (st1) *reinterpret_cast<bf16x8*>(g.out + o1) = epi_sel(lo8, ovA, recv);
+                            if (st2) *reinterpret_cast<bf16x8*>(g.out + o2) = epi_sel(lo8, recv, ovB);
+                        }
+                    }
+                }
+            } else {
 #pragma unroll
             for (int a2 = 0; a2 < FC / 2; ++a2) {
                 const int c = n0 + wn * (BN / WN) + a2 * 32 + par * 16 + half * 8;
@@ -387,10 +517,19 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) igemm_kernel(IgemmArgs g) {
                     epi_swap8(acc[2 * a2][b], acc[2 * a2 + 1][b], v);
                     if (GUARD && orow[b] < 0) continue;
                     const long long o = orow[b] + c;
-                    bf16x8 av;
-                    if (EPI == EPI_MASK) av = PRELOAD ? avs[a2][b] : *reinterpret_cast<const bf16x8*>(g.act + o);
-                    epi_emit8<EPI>(g, o, v, sv, bv, av);
+                    bf16x8 av = {};
+                    if (MASKED) av = PRELOAD ? avs[a2][b] : *reinterpret_cast<const bf16x8*>(g.act + o);
+                    const bf16x8 ov = epi_value8<EPI>(g, v, sv, bv, av);
+                    if constexpr (EPI == EPI_UNPOOL) {
+                        bf16x8 r[4];
+                        epi_route4(ov, PRELOAD ? pks[a2][b] : g.pool_idx[o >> 3], r);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) *reinterpret_cast<bf16x8*>(g.out + o00[b] + c + (k & 1) * g.NOUT + (k >> 1) * down) = r[k];
+                    } else {
+                        *reinterpret_cast<bf16x8*>(g.out + o) = ov;
+                    }
                 }
+            }
             }
         };
         if (m0 + BM <= Mc) run(std::false_type()); else run(std::true_type());
@@ -1032,6 +1171,15 @@ int launch_igemm8_splitk(IgemmArgs& g, int ks, int want_epi, hipStream_t s, cons
 template <int EPI, bool SUB>
 int dispatch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
     const int force = yfs_knob(YFS_KNOB_IGEMM_TILE);
+    if constexpr (EPI == EPI_UNPOOL) {
+        // dgrad of the layer behind a pool, writing that pool's input gradient (feat.4 / 9 / 20, all 1x1): store-bound (four
+        // output pixels per GEMM row), on the small kernel only
+        static_assert(!SUB, "EPI_UNPOOL is a stride-1 epilogue");
+        if (g.NOUT % 192 == 0 && g.NOUT % 128 != 0) return launch_igemm<128, 192, 2, 2, 2, EPI, false>(g, s, name);
+        if (g.NOUT % 128 != 0) return launch_igemm<128, 64, 2, 2, 2, EPI, false>(g, s, name);
+        if (force == 128 || (force == 0 && g.KH * g.KW > 1)) return launch_igemm<128, 128, 2, 2, 2, EPI, false>(g, s, name);
+        return launch_igemm<64, 128, 2, 2, 2, EPI, false>(g, s, name);
+    } else {
     if constexpr (EPI == EPI_MASK && !SUB) {
         // feat.2's dgrad (192 output channels, K = 2304): the 8-phase kernel with a 192-channel tile (knob 192 forces
         // it, knob 128 the small kernel)
@@ -1111,6 +1259,7 @@ int dispatch_igemm(IgemmArgs& g, hipStream_t s, const char* name) {
     // L20 29.4 -> 28.2 (the 1x1 forward launches are slower with this tile and stay on 128x128)
     if (force == 0 && !SUB && EPI == EPI_MASK && g.KH * g.KW == 1) return launch_igemm<64, 128, 2, 2, 2, EPI, SUB>(g, s, name);
     return launch_igemm<128, 128, 2, 2, 2, EPI, SUB>(g, s, name);
+    }
 }
 
 int check_conv_shape(const char* fn, int64_t N, int H, int W, int Cin, int Cout, int K, int stride) {
@@ -1240,6 +1389,19 @@ YFS_API int yfs_conv2d_dgrad_ws_bf16(const void* dz, const void* wt, const void*
     }
     return x_act ? dispatch_igemm<EPI_MASK, true>(g, s, "yfs_conv2d_dgrad_bf16")
                  : dispatch_igemm<EPI_NONE, true>(g, s, "yfs_conv2d_dgrad_bf16");
+}
+
+YFS_API int yfs_conv2d_dgrad_unpool_bf16(const void* dz, const void* wt, const void* y_pooled, const void* pool_idx, void* dx_full,
+                                         int64_t N, int H, int W, int Cin, int Cout, int K, float slope, void* stream) {
+    YFS_REQUIRE(dz && wt && y_pooled && pool_idx && dx_full, YFS_ERR_INVALID_ARG, "yfs_conv2d_dgrad_unpool_bf16: null pointer");
+    int rc = check_conv_shape("yfs_conv2d_dgrad_unpool_bf16", N, H, W, Cout, Cin, K, 1);   // roles swap: reduce over Cout
+    if (rc) return rc;
+    YFS_REQUIRE(N * 4 * H * W * Cin * 2 < 0xFFF00000ll, YFS_ERR_UNSUPPORTED,
+                "yfs_conv2d_dgrad_unpool_bf16: the full-resolution gradient exceeds 4 GiB (split the batch)");
+    IgemmArgs g = {};
+    dgrad_args(g, dz, wt, y_pooled, dx_full, N, H, W, Cin, Cout, K, 1, slope);
+    g.pool_idx = (unsigned short*)pool_idx;   // read only in this form
+    return dispatch_igemm<EPI_UNPOOL, false>(g, (hipStream_t)stream, "yfs_conv2d_dgrad_unpool_bf16");
 }
 
 // =============================== wgrad ==========================================================

@@ -24,6 +24,9 @@ SLOPE = 0.1
 _TWO_STREAMS = os.environ.get("YFS_WGRAD_STREAM", "1") != "0"
 _FUSE_POOL = os.environ.get("YFS_FUSE_POOL", "1") != "0"
 _FUSE_STEM_POOL_BWD = os.environ.get("YFS_FUSE_STEM_POOL_BWD", "1") != "0"
+# pool backward inside the dgrad of the block behind it (conv_ops.conv_dgrad_unpool): bit-identical, and measured no faster
+# than the two launches inside the step (10.62 vs 10.63 ms, same box), so it is opt-in
+_FUSE_UNPOOL = os.environ.get("YFS_FUSE_UNPOOL", "0") == "1"
 _FUSE_FC = os.environ.get("YFS_FUSE_FC", "1") != "0"
 
 
@@ -317,8 +320,12 @@ class _BackboneFn(torch.autograd.Function):
         # epilogue (fp32, before the one rounding to bf16) and pool backward only routes.  A pool that ends the chain
         # has no dgrad after it and applies the mask itself.
         pooled = None
+        unpooled = False     # the dgrad of block i + 1 already carried its gradient through pool i
         for i in range(last, -1, -1):
             if stages[i] == "P":
+                if unpooled:
+                    unpooled = False
+                    continue
                 if _FUSE_STEM_POOL_BWD and i == 1 and plans[0] is not None and plans[0].stem:
                     # nothing but the stem's weight gradient reads this pool's input gradient: that kernel builds
                     # its dz tiles from the pooled side itself, and the full-resolution tensor is never written
@@ -348,7 +355,13 @@ class _BackboneFn(torch.autograd.Function):
             grads[pi], grads[pi + 1] = dw, db
             if i == 0:
                 break
-            g = co.conv_dgrad(g, plan.wt16, acts[i - 1].shape[2:], plan.stride, x_act=acts[i - 1], slope=SLOPE)
+            stem_pool = _FUSE_STEM_POOL_BWD and i == 2 and plans[0] is not None and plans[0].stem
+            if _FUSE_UNPOOL and stages[i - 1] == "P" and plan.stride == 1 and not stem_pool and acts[i - 1].shape[1] % 64 == 0:
+                # a pool in front of this block: its backward is four stores per GEMM row in this dgrad's epilogue
+                g = co.conv_dgrad_unpool(g, plan.wt16, acts[i - 1], gins[i - 1], slope=SLOPE)
+                unpooled = True
+            else:
+                g = co.conv_dgrad(g, plan.wt16, acts[i - 1].shape[2:], plan.stride, x_act=acts[i - 1], slope=SLOPE)
         if side is not None:
             main.wait_stream(side)
         ctx.acts = ctx.gins = ctx.plans = ctx.params = None
