@@ -19,6 +19,7 @@
 //     fragments are read with ds_read_b64_tr_b16 (hardware transpose); split-K over pixels with fp32
 //     partial slabs and a fixed-order reduction (deterministic).
 #include <algorithm>
+#include <atomic>
 #include <type_traits>
 #include "yfs_common.h"
 #include <cstdlib>
@@ -660,30 +661,41 @@ constexpr int B8_EPI_STRIDE = 256 * 4 + 16;   // epilogue: four slabs of <= 64 r
 // and their counts (224, 448, 896, ...) fill 256 CUs to 87.5-100 % where 196 / 392 / 784 tiles of 256 rows fill 76.6 %.
 #ifdef YFS_IG8_TIMING
 __device__ long long yfs_ig8_dbg[8];
-#define IG8_T(k) do { if (blockIdx.x == 17 && threadIdx.x == 0) yfs_ig8_dbg[k] = clock64(); } while (0)
+// timeline of every workgroup of the launch (first 8192): [block][0..4] = the section clocks, [block][5] = HW_ID | XCC_ID << 32,
+// so that the host can line the workgroups of one CU up and see what lies between one's end and the next one's start
+__device__ long long yfs_ig8_tl[8192 * 6];
+#define IG8_T(k, slot) do { if (threadIdx.x == 0) { const long long c_ = clock64(); if ((slot) == 17) yfs_ig8_dbg[k] = c_; \
+    if ((slot) < 8192) { yfs_ig8_tl[(slot) * 6 + (k)] = c_; if ((k) == 0) yfs_ig8_tl[(slot) * 6 + 5] = \
+        (long long)(unsigned)__builtin_amdgcn_s_getreg(63492) | ((long long)(unsigned)__builtin_amdgcn_s_getreg(63508) << 32); } } } while (0)
 #else
-#define IG8_T(k) do { } while (0)
+#define IG8_T(k, slot) do { } while (0)
 #endif
 // FW1 = channel fragments per wave in the SECOND weight half-tile: 2 -> 256-channel tile, 1 -> 192-channel tile (W1 holds
 // 64 rows, its MFMA blocks are half as long): feat.2's dgrad writes 192 channels.
+// Persistent forms: all but the pool-fused epilogue (it parks the tile in the LDS the next tile's loads would land in), the
+// 256 x 256 tile (128 accumulators + the epilogue's preloaded operands + the next tile's staging state do not fit in 256
+// registers: the compiler spills, and a scratch access next to the counted vmcnt waits would miscount them) and the
+// split-K form (its grids are at most one workgroup per CU by construction, and with the K-range state carried around a
+// tile loop the compiler keeps it in vector registers: feat.26 forward 71 -> 77 us).
+template <int EPI, int FP1, int FW1>
+constexpr bool igemm8_persistent() { return EPI != EPI_POOL && EPI != EPI_PARTIAL && !(FP1 == 4 && FW1 == 2); }
+
 template <int EPI, int FP1, int FW1 = 2>
 __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
     constexpr int BM = 128 + FP1 * 32, BN = 128 + FW1 * 64;
-    IG8_T(0);
+    constexpr bool PERSIST = igemm8_persistent<EPI, FP1, FW1>();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __attribute__((address_space(3))) void* lds_ptr;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    int logical = xcd_remap(blockIdx.x, g.mtiles * g.ntiles * (EPI == EPI_PARTIAL ? g.ksplit : 1));
-    int split = 0;
-    if (EPI == EPI_PARTIAL) {   // K-split outermost: the blocks of one split share its slice of the weights in L2
-        split = logical / (g.mtiles * g.ntiles);
-        logical -= split * (g.mtiles * g.ntiles);
-    }
-    const int nt = logical % g.ntiles, mt = logical / g.ntiles;
-    const int m0 = mt * BM, n0 = nt * BN;
     const int Mc = g.M;
+    // Persistent (igemm8_persistent): the grid is one workgroup per CU and workgroup w takes tiles w,
+    // w + G, w + 2G, ... (virtual block ids: the XCD-aware order is that of a grid of one workgroup per tile).  The epilogue
+    // touches no LDS, so the next tile's coordinates are computed and its first two K-steps are on their way into the ring
+    // BEFORE the finished tile's epilogue runs: neither the workgroup turn-over (~1.7 K cycles) nor the cold first loads
+    // (4-7 K cycles from entry to the first MFMA, tools/probes/igemm8_turnover.py) sit between two main loops.
+    const int tiles_mn = g.mtiles * g.ntiles, total = tiles_mn * (EPI == EPI_PARTIAL ? g.ksplit : 1);
 
     // ---- staging coordinates: 4 pixel rows and 4 weight rows per thread (2 per half-tile) -----------------------------
     const int chunk = (lane & 7) ^ (lane >> 3);   // source-side XOR swizzle (see igemm_kernel)
@@ -693,23 +705,14 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
     // st[4 + j] = (bh << 16) | (bw & 0xFFFF), that pixel's row / column (both within +-16 K: dispatch_igemm checks)
     unsigned* const st = reinterpret_cast<unsigned*>(smem + B8_LDS) + tid * 8;
     const unsigned ktot = (unsigned)(g.KH * g.KW * g.C);
-    const unsigned wrow = (unsigned)(n0 + wave * 16 + (lane >> 3)) * ktot * 2 + chunk * 16;
     const int cchunks = g.C / BK;
     const int ktotal = g.KH * g.KW * cchunks;
-    // this block's K-steps: [ks0, kend) of the layer's ktotal (all of them unless EPI_PARTIAL)
-    const int ks0 = EPI == EPI_PARTIAL ? split * g.ksteps_per_split : 0;
-    const int kend = EPI == EPI_PARTIAL ? (ks0 + g.ksteps_per_split < ktotal ? ks0 + g.ksteps_per_split : ktotal) : ktotal;
-    const int nit = kend - ks0;
-
-    // position of the tile the staging state describes: tile ts = (kh, kw, cc); xoff = this thread's source offsets
-    // for that tap (recomputed when the tap changes)
-    int kh = 0, kw = 0, cc = 0, ts = ks0;
-    if (EPI == EPI_PARTIAL) {
-        const int tap0 = ks0 / cchunks;
-        cc = ks0 - tap0 * cchunks;
-        kh = tap0 / g.KW;
-        kw = tap0 - kh * g.KW;
-    }
+    // the tile the staging state describes: rows m0.., channels n0.., K-steps [ks0, kend) of the layer's ktotal (all of them
+    // unless EPI_PARTIAL); ts = (kh, kw, cc) = the K-step staged next; xoff = this thread's source offsets for that tap
+    // (recomputed when the tap changes)
+    int m0 = 0, n0 = 0, split = 0, kend = 0, nit = 0;
+    unsigned wrow = 0;
+    int kh = 0, kw = 0, cc = 0, ts = 0;
     unsigned xoff[4];
     constexpr unsigned kOutside = 0xFFF00000u;
     auto tap_offsets = [&]() {
@@ -731,7 +734,10 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
         }
     };
     auto stage_P = [&](int h, int buf) {
-        const unsigned so = (unsigned)(cc * (BK * 2));   // wave-uniform part goes in the scalar offset
+        // wave-uniform part goes in the scalar offset.  (readfirstlane: in some instantiations the compiler keeps the K-step
+        // state in vector registers once it is carried around the tile loop, and would wrap every LDS-DMA in a waterfall
+        // loop over this operand: 2200 -> 3080 cycles per K-step)
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(cc * (BK * 2));
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const unsigned off = xoff[h * 2 + i];
@@ -742,7 +748,7 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
     auto stage_W = [&](int h, int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const unsigned so = ((unsigned)(h * 128 + i * 8) * ktot + (unsigned)ts * BK) * 2;
+            const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)(((unsigned)(h * 128 + i * 8) * ktot + (unsigned)ts * BK) * 2));
             const unsigned off = wrow;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(smem + buf * B8_BUF + (2 + h) * B8_HALF + (wave * 2 + i) * 1024),
                                                      16, off, so, 0, 0);
@@ -789,49 +795,72 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    // prologue: tile 0 complete, W0 / P0 / W1 of tile 1 in flight (the steady state at the top of a K-step).  The weight
-    // half-tiles of tile 0 need no pixel coordinates: they are on their way while those are computed
-    stage_W(0, 0); stage_W(1, 0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {   // j = half * 2 + i: tile row half*128 + wave*16 + i*8 + (lane >> 3)
-        const int hr = wave * 16 + (j & 1) * 8 + (lane >> 3);   // row inside the half-tile
-        const int m = m0 + (j >> 1) * 128 + hr;
-        if (m < Mc && (j < 2 || hr < FP1 * 32)) {
-            int n, oh, ow;
-            // (host-prepared multipliers: four rows x two divisions per thread were ~280 instructions of every tile's prologue)
-            if (EPI == EPI_POOL) {   // window-major row order (see igemm_kernel); div_hw / div_w divide by the pooled grid
-                const int q = m >> 2, sub = m & 3;
-                n = (int)fdiv((unsigned)q, g.div_hw);
-                const int r = q - n * (int)g.div_hw.d;
-                const int py = (int)fdiv((unsigned)r, g.div_w), px = r - py * (int)g.div_w.d;
-                oh = 2 * py + (sub >> 1);
-                ow = 2 * px + (sub & 1);
-            } else {
-                n = (int)fdiv((unsigned)m, g.div_hw);
-                const int rem = m - n * (int)g.div_hw.d;
-                oh = (int)fdiv((unsigned)rem, g.div_w);
-                ow = rem - oh * (int)g.div_w.d;
-            }
-            const int bh = oh * g.s_mul - g.pad, bw = ow * g.s_mul - g.pad;
-            st[4 + j] = ((unsigned)bh << 16) | ((unsigned)bw & 0xFFFFu);
-            st[j] = (unsigned)(((long long)(n * g.H + bh) * g.W + bw) * g.PS * 2) + chunk * 16;
-        } else {
-            st[4 + j] = 0xC000C000u;   // (-16384, -16384): outside for every tap
-            st[j] = 0;
+    // Staging state of virtual block vb, and its first K-step (tile 0) plus W0 / P0 / W1 of its second on their way: the
+    // steady state at the top of a K-step once tile 0 has landed.  The weight half-tiles of tile 0 need no pixel
+    // coordinates: they are on their way while those are computed
+    auto begin_tile = [&](int vb) {
+        IG8_T(0, vb);
+        auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };   // (the divisions run on the vector ALU)
+        int logical = uni(xcd_remap(vb, total));
+        split = 0;
+        if (EPI == EPI_PARTIAL) {   // K-split outermost: the blocks of one split share its slice of the weights in L2
+            split = uni(logical / tiles_mn);
+            logical -= split * tiles_mn;
         }
-    }
-    tap_offsets();
-    stage_P(0, 0); stage_P(1, 0);
-    if (nit > 1) {
-        advance();
-        stage_W(0, 1); stage_P(0, 1); stage_W(1, 1);
-        wait_vmcnt<6>();
-    } else {
-        wait_vmcnt<0>();
-    }
-    bar();
-    if (wm == 1) bar();   // waves 4-7 run one barrier behind waves 0-3 from here on
-    IG8_T(1);
+        const int nt = uni(logical % g.ntiles), mt = uni(logical / g.ntiles);
+        m0 = mt * BM;
+        n0 = nt * BN;
+        wrow = (unsigned)(n0 + wave * 16 + (lane >> 3)) * ktot * 2 + chunk * 16;
+        const int ks0 = EPI == EPI_PARTIAL ? split * g.ksteps_per_split : 0;
+        kend = EPI == EPI_PARTIAL ? (ks0 + g.ksteps_per_split < ktotal ? ks0 + g.ksteps_per_split : ktotal) : ktotal;
+        nit = kend - ks0;
+        kh = kw = cc = 0;
+        ts = ks0;
+        if (EPI == EPI_PARTIAL) {
+            const int tap0 = uni(ks0 / cchunks);
+            cc = uni(ks0 - tap0 * cchunks);
+            kh = uni(tap0 / g.KW);
+            kw = uni(tap0 - kh * g.KW);
+        }
+        stage_W(0, 0); stage_W(1, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {   // j = half * 2 + i: tile row half*128 + wave*16 + i*8 + (lane >> 3)
+            const int hr = wave * 16 + (j & 1) * 8 + (lane >> 3);   // row inside the half-tile
+            const int m = m0 + (j >> 1) * 128 + hr;
+            if (m < Mc && (j < 2 || hr < FP1 * 32)) {
+                int n, oh, ow;
+                // (host-prepared multipliers: four rows x two divisions per thread were ~280 instructions of every tile's prologue)
+                if (EPI == EPI_POOL) {   // window-major row order (see igemm_kernel); div_hw / div_w divide by the pooled grid
+                    const int q = m >> 2, sub = m & 3;
+                    n = (int)fdiv((unsigned)q, g.div_hw);
+                    const int r = q - n * (int)g.div_hw.d;
+                    const int py = (int)fdiv((unsigned)r, g.div_w), px = r - py * (int)g.div_w.d;
+                    oh = 2 * py + (sub >> 1);
+                    ow = 2 * px + (sub & 1);
+                } else {
+                    n = (int)fdiv((unsigned)m, g.div_hw);
+                    const int rem = m - n * (int)g.div_hw.d;
+                    oh = (int)fdiv((unsigned)rem, g.div_w);
+                    ow = rem - oh * (int)g.div_w.d;
+                }
+                const int bh = oh * g.s_mul - g.pad, bw = ow * g.s_mul - g.pad;
+                st[4 + j] = ((unsigned)bh << 16) | ((unsigned)bw & 0xFFFFu);
+                st[j] = (unsigned)(((long long)(n * g.H + bh) * g.W + bw) * g.PS * 2) + chunk * 16;
+            } else {
+                st[4 + j] = 0xC000C000u;   // (-16384, -16384): outside for every tap
+                st[j] = 0;
+            }
+        }
+        tap_offsets();
+        stage_P(0, 0); stage_P(1, 0);
+        if (nit > 1) {
+            advance();
+            stage_W(0, 1); stage_P(0, 1); stage_W(1, 1);
+        }
+    };
+    int vb = (int)blockIdx.x;
+    begin_tile(vb);
+    if (nit > 1) wait_vmcnt<6>(); else wait_vmcnt<0>();
 
     const std::integral_constant<int, 4> F4;
     const std::integral_constant<int, FP1> F1;
@@ -867,6 +896,10 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
         mfma16(acc[1][0], w0f, F1, A2);
         bar();
     };
+    for (;;) {   // one pass per tile of this workgroup
+    bar();
+    if (wm == 1) bar();   // waves 4-7 run one barrier behind waves 0-3 from here on
+    IG8_T(1, vb);
     int t = 0;
     for (; t + 1 < nit; t += 2) {
         tile(t, std::integral_constant<int, 0>());
@@ -874,7 +907,11 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
     }
     if (t < nit) tile(t, std::integral_constant<int, 0>());
     if (wm == 0) bar();   // catch up with waves 4-7: every wave is past its last fragment read after this
-    IG8_T(2);
+    IG8_T(2, vb);
+    // the finished tile, and whether another follows (its prologue goes out from inside the epilogue)
+    const int cm0 = m0, cn0 = n0, csplit = split, cvb = vb;
+    vb += (int)gridDim.x;
+    const bool more = PERSIST && vb < total;
 
     // ---- epilogue ---------------------------------------------------------------------------------------------------
     // acc[ph][wh][a][b][r] = out[pixel ph*128 + wm*NF*16 + b*16 + (lane&15)][chan wh*128 + wn*NA*16 + a*16 + (lane>>4)*4 + r]
@@ -883,59 +920,68 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
     if constexpr (EPI != EPI_POOL) {
         // straight from the accumulators (see epi_swap8)
         const int par = fk & 1, half = fk >> 1;
-        float bv[8], sv[8];
         // GUARD = the tile hangs over the end of the GEMM's rows: every row is tested.  Whole tiles (all of them at this
-        // network's sizes) run without tests in one basic block, so the activation loads of the masked form and the stores
-        // of one fragment pair overlap the arithmetic of the next
+        // network's sizes) run without tests in one basic block, so the stores of one fragment pair overlap the arithmetic
+        // of the next.  Everything the epilogue LOADS (bias / scale rows; in the masked form of a whole tile all 14-16
+        // activation vectors of the wave: one in flight per fragment pair, what the compiler schedules by itself, left it
+        // waiting ~700 cycles on each) is requested first, then the next tile's prologue goes out, then the arithmetic and
+        // the stores run: vmcnt retires in order, so a load requested after the prologue's DMA would wait for all of it.
         auto run = [&](auto guard_tag) {
         constexpr bool GUARD = decltype(guard_tag)::value;
-        // masked form, whole tile: all 16 (14) activation loads of the wave go out first; one load in flight per fragment
-        // pair (what the compiler schedules by itself) left the epilogue waiting ~700 cycles on each
         constexpr bool PRELOAD = EPI == EPI_MASK && !GUARD;
+        // after the swap: NA == 2 pairs the two channel fragments of one pixel fragment (lanes with odd fk own fragment
+        // a = 1); NA == 1 pairs pixel fragments b, b + 1 of the only channel fragment (lanes with odd fk own rows of b + 1)
+        int cb[2], cc8[2];   // first channel of the wave's slice of weight half wh; of this lane's 8-channel run in it
+        float bvs[2][8], svs[2][8];
         bf16x8 avs[2][2][4];
-        if (PRELOAD) {
 #pragma unroll
-            for (int wh = 0; wh < 2; ++wh) {
-                const int NA = wh == 1 ? FW1 : 2;
-                const int c = n0 + wh * 128 + wn * (NA * 16) + (NA == 2 ? par * 16 : 0) + half * 8;
+        for (int wh = 0; wh < 2; ++wh) {
+            const int NA = wh == 1 ? FW1 : 2;
+            cb[wh] = cn0 + wh * 128 + wn * (NA * 16);
+            cc8[wh] = cb[wh] + (NA == 2 ? par * 16 : 0) + half * 8;
+            if (EPI == EPI_BIAS_LEAKY) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    bvs[wh][j] = g.bias[cc8[wh] + j];
+                    svs[wh][j] = g.scale ? g.scale[cc8[wh] + j] : 1.0f;
+                }
+            }
+            if (PRELOAD) {
 #pragma unroll
                 for (int ph = 0; ph < 2; ++ph) {
                     const int NF = ph == 1 ? FP1 : 4;
-                    const int r0 = m0 + ph * 128 + wm * (NF * 16) + frow;
+                    const int r0 = cm0 + ph * 128 + wm * (NF * 16) + frow;
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
                         if (b >= NF || (NA == 1 && ((b & 1) || b + 1 >= NF))) continue;
                         const int m = r0 + (NA == 2 ? b : b + par) * 16;
-                        avs[wh][ph][b] = *reinterpret_cast<const bf16x8*>(g.act + (long long)m * g.NOUT + c);
+                        avs[wh][ph][b] = *reinterpret_cast<const bf16x8*>(g.act + (long long)m * g.NOUT + cc8[wh]);
                     }
                 }
             }
         }
-        auto emit = [&](int m, int c, float (&v)[8], const bf16x8& pre) {   // 8 channels from c of output row m
-            if (GUARD && m >= Mc) return;
-            const long long o = (long long)m * g.NOUT + c;
-            bf16x8 av;
-            if (EPI == EPI_MASK) av = PRELOAD ? pre : *reinterpret_cast<const bf16x8*>(g.act + o);
-            epi_emit8<EPI>(g, o, v, sv, bv, av);
-        };
+        if constexpr (PERSIST) {
+            if (more) {
+                __builtin_amdgcn_sched_barrier(0);
+                begin_tile(vb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
 #pragma unroll
         for (int wh = 0; wh < 2; ++wh) {
             const int NA = wh == 1 ? FW1 : 2;
-            const int cbase = n0 + wh * 128 + wn * (NA * 16);
-            // after the swap: NA == 2 pairs the two channel fragments of one pixel fragment (lanes with odd fk own fragment
-            // a = 1); NA == 1 pairs pixel fragments b, b + 1 of the only channel fragment (lanes with odd fk own rows of b + 1)
-            const int c = cbase + (NA == 2 ? par * 16 : 0) + half * 8;
-            if (EPI == EPI_BIAS_LEAKY) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    bv[j] = g.bias[c + j];
-                    sv[j] = g.scale ? g.scale[c + j] : 1.0f;
-                }
-            }
+            const int cbase = cb[wh], c = cc8[wh];
+            auto emit = [&](int m, float (&v)[8], const bf16x8& pre) {   // the lane's 8 channels of output row m
+                if (GUARD && m >= Mc) return;
+                const long long o = (long long)m * g.NOUT + c;
+                bf16x8 av;
+                if (EPI == EPI_MASK) av = PRELOAD ? pre : *reinterpret_cast<const bf16x8*>(g.act + o);
+                epi_emit8<EPI>(g, o, v, svs[wh], bvs[wh], av);
+            };
 #pragma unroll
             for (int ph = 0; ph < 2; ++ph) {
                 const int NF = ph == 1 ? FP1 : 4;
-                const int r0 = m0 + ph * 128 + wm * (NF * 16) + frow;
+                const int r0 = cm0 + ph * 128 + wm * (NF * 16) + frow;
                 if (EPI == EPI_PARTIAL) {   // the raw fp32 sums of this block's K range; the epilogue runs in the reduction
 #pragma unroll
                     for (int a = 0; a < 2; ++a)
@@ -944,7 +990,7 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
                             if (a >= NA || b >= NF) continue;
                             const int m = r0 + b * 16;
                             if (!GUARD || m < Mc)
-                                *reinterpret_cast<f32x4*>(g.partial + ((long long)split * Mc + m) * g.NOUT + cbase + a * 16 + fk * 4) =
+                                *reinterpret_cast<f32x4*>(g.partial + ((long long)csplit * Mc + m) * g.NOUT + cbase + a * 16 + fk * 4) =
                                     acc[ph][wh][a][b];
                         }
                 } else if (NA == 2) {
@@ -953,14 +999,14 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
                         if (b >= NF) continue;
                         float v[8];
                         epi_swap8(acc[ph][wh][0][b], acc[ph][wh][1][b], v);
-                        emit(r0 + b * 16, c, v, avs[wh][ph][b]);
+                        emit(r0 + b * 16, v, avs[wh][ph][b]);
                     }
                 } else {
 #pragma unroll
                     for (int b = 0; b + 1 < NF; b += 2) {
                         float v[8];
                         epi_swap8(acc[ph][wh][0][b], acc[ph][wh][0][b + 1], v);
-                        emit(r0 + (b + par) * 16, c, v, avs[wh][ph][b]);
+                        emit(r0 + (b + par) * 16, v, avs[wh][ph][b]);
                     }
                     if (NF & 1) {   // (224 x 192 tile: a third pixel fragment without a partner leaves as 8 B per lane)
                         const int m = r0 + (NF - 1) * 16, c4 = cbase + fk * 4;
@@ -988,7 +1034,7 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
             }
         }
         };
-        if (m0 + BM <= Mc) run(std::false_type()); else run(std::true_type());
+        if (cm0 + BM <= Mc) run(std::false_type()); else run(std::true_type());
     } else {
         // EPI_POOL: the fp32 tile through LDS (the 2x2 windows span four pixel rows of the tile = four lanes of a fragment
         // column, and the window's argmax goes out beside the maximum).  Two passes (pixel halves); in each, both wave rows
@@ -1052,11 +1098,19 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
             if (ph == 0) __syncthreads();
         }
     }
-    IG8_T(3);
-#ifdef YFS_IG8_TIMING
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    IG8_T(4);
-#endif
+    IG8_T(3, cvb);
+    // Everything of this tile has left and the next tile's first K-step has landed after this wait (~1 K cycles after the
+    // last store was issued; the second K-step's half-tiles were requested a whole epilogue ago).  The builtin, not the
+    // inline-asm wait, and on the way out of the last tile too: the compiler has to KNOW that nothing of the epilogue is
+    // outstanding at the top of the tile loop, on every path its data flow merges there.  Otherwise it protects the
+    // fragment registers, which the epilogue's loads reused, with vmcnt(0) waits of its own at the top of every K-step
+    // and the loop loses its two K-steps of load run-ahead (85 K -> 90 K cycles per feat.7 tile).
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0); expcnt and lgkmcnt untouched
+    IG8_T(4, cvb);
+    if (!more) break;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) (&acc[0][0][0][0])[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 }
 
 #ifdef YFS_IG8_TIMING
@@ -1064,8 +1118,26 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
 extern "C" __attribute__((visibility("default"))) int yfs_debug_ig8_times(long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(yfs_ig8_dbg), 8 * sizeof(long long));
 }
+extern "C" __attribute__((visibility("default"))) int yfs_debug_ig8_timeline(long long* out, int nblocks) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(yfs_ig8_tl), (size_t)(nblocks < 8192 ? nblocks : 8192) * 6 * sizeof(long long));
+}
 namespace {
 #endif
+// CUs of the current device (a multiple of 8 on every CDNA part: the XCD-aware tile order relies on workgroup w and
+// workgroup w + cu_count() landing on the same XCD, see xcd_remap)
+int cu_count() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    int n = cached[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        n -= n % 8;
+        cached[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
 template <int EPI, int FP1, int FW1 = 2>
 int launch_igemm8(IgemmArgs& g, hipStream_t s, const char* name) {
     g.mtiles = (int)yfs_cdiv(g.M, 128 + FP1 * 32);
@@ -1076,7 +1148,13 @@ int launch_igemm8(IgemmArgs& g, hipStream_t s, const char* name) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, B8_LDS_IG);
     YFS_REQUIRE(e == hipSuccess, YFS_ERR_LAUNCH, "%s: cannot reserve %d bytes of LDS", name, B8_LDS_IG);
     const int copies = EPI == EPI_PARTIAL ? g.ksplit : 1;
-    kern<<<dim3((unsigned)(g.mtiles * g.ntiles * copies)), dim3(512), B8_LDS_IG, s>>>(g);
+    int grid = g.mtiles * g.ntiles * copies;
+    if (igemm8_persistent<EPI, FP1, FW1>()) {   // one workgroup per CU walks the tiles (the kernel strides by gridDim.x)
+        const int cus = cu_count();
+        YFS_REQUIRE(cus > 0, YFS_ERR_LAUNCH, "%s: cannot read the device's CU count", name);
+        if (grid > cus) grid = cus;
+    }
+    kern<<<dim3((unsigned)grid), dim3(512), B8_LDS_IG, s>>>(g);
     YFS_CHECK_LAUNCH(name);
     yfs_note_kernel("igemm8_kernel<%d,%d,epi%d>", 128 + FP1 * 32, 128 + FW1 * 64, EPI);
     return YFS_OK;
