@@ -1910,7 +1910,11 @@ __device__ __forceinline__ void dma16_asm(__amdgpu_buffer_rsrc_t rsrc, unsigned 
         "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
+#ifdef YFS_IG8_TIMING   // (the section clocks make the compiler keep these two wave-uniform values in vector registers)
+        : "s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane((int)soff))
+#else
         : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+#endif
         : "memory");
 }
 
@@ -1922,6 +1926,7 @@ __global__ void __launch_bounds__(512, 2) wgrad8_kernel(WgradArgs g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
+    IG8_T(0, (int)blockIdx.x);   // (tools/probes/wgrad8_sections.py)
     const int taps = g.KH * g.KW;
     const int inner = g.citiles * taps;
     const int logical = xcd_remap(blockIdx.x, g.cotiles * inner * g.splits);
@@ -2076,6 +2081,7 @@ __global__ void __launch_bounds__(512, 2) wgrad8_kernel(WgradArgs g) {
     }
     bar();
     if (wm == 1) bar();
+    IG8_T(1, (int)blockIdx.x);
 
     auto tile = [&](int t, auto buf_tag) {
         constexpr int BUF = decltype(buf_tag)::value;
@@ -2123,6 +2129,7 @@ __global__ void __launch_bounds__(512, 2) wgrad8_kernel(WgradArgs g) {
     }
     if (t < nit) tile(t, std::integral_constant<int, 0>());
     if (wm == 0) bar();
+    IG8_T(2, (int)blockIdx.x);
 
     // ---- epilogue: transpose through LDS, four slabs of 64 co rows; rows leave as whole ci-contiguous runs --------------
     // acc[xh][zh][a][b][r] = dw[co0 + zh*128 + wn*32 + a*16 + (lane>>4)*4 + r][tap][ci0 + xh*XH + wm*FX*16 + b*16 + (lane&15)]
@@ -2164,6 +2171,11 @@ __global__ void __launch_bounds__(512, 2) wgrad8_kernel(WgradArgs g) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) drow[co0 + zh * 128 + wn * 32 + a * 16 + g4 * 4 + r] = accdb[zh][a][r];
     }
+    IG8_T(3, (int)blockIdx.x);
+#ifdef YFS_IG8_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    IG8_T(4, (int)blockIdx.x);
+#endif
 }
 
 // dw[i] = (accumulate ? dw[i] : 0) + sum_s partial[s][i].  G groups of threads share one float4 column: group r
