@@ -10,10 +10,12 @@
 //     4 consecutive output channels of one pixel.  Operands go global -> LDS directly (buffer_load ... lds,
 //     16 B per lane; conv padding and tile tails are out-of-range offsets that the hardware zero-fills), LDS
 //     rows of 128 B XOR-swizzled by (row & 7) on the SOURCE side so the fragment ds_read_b128 is conflict
-//     free; epilogue goes through an fp32 LDS tile so bias (or folded-BN scale/shift) / LeakyReLU / the
-//     activation-derivative mask run in fp32 and the bf16 result leaves as whole 16 B per lane.
+//     free; the epilogue works on the accumulators in place: bias (or folded-BN scale/shift) / LeakyReLU / the
+//     activation-derivative mask run in fp32, one v_permlane16_swap per register pairs two fragments so that the
+//     bf16 result leaves as whole 16 B per lane (epi_swap8; only the pool-fused form goes through an fp32 LDS tile).
 //     igemm_kernel: BM x BN x 64 tiles, 4 or 8 waves, 2-stage ring; igemm8_kernel: 256 (224) x 256 tiles,
-//     8 waves in two staggered groups, half-tiles staged two K-steps ahead (the long-K 3x3 layers).
+//     8 waves in two staggered groups, half-tiles staged two K-steps ahead, one persistent workgroup per CU that
+//     issues the next tile's first loads from inside the epilogue (the long-K 3x3 layers).
 //   wgrad: dw[co][tap][ci] = sum_pixel dz[pixel][co] * x[gather(pixel,tap)][ci] — both operands have the
 //     reduction index (pixel) as the slow axis, so the LDS tiles keep [pixel][channel] rows and the
 //     fragments are read with ds_read_b64_tr_b16 (hardware transpose); split-K over pixels with fp32
