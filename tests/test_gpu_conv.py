@@ -523,3 +523,45 @@ def test_dgrad_carried_through_the_pool_in_front_is_bit_identical(n, cin, cout, 
     assert got.shape == ref.shape == (n, cin, 2 * hw, 2 * hw)
     assert torch.equal(got, ref)
     assert float((got != 0).float().mean()) < 0.2501      # one position per window
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("op,n,cin,cout,knob", [("fwd", 5, 64, 256, 87), ("dgrad", 5, 256, 64, 87), ("dgrad_plain", 5, 256, 64, 87),
+                                                ("dgrad", 6, 192, 64, 192)])
+def test_persistent_8phase_kernel_on_more_tiles_than_cus_with_a_ragged_last_tile(op, n, cin, cout, knob):
+    """igemm8_kernel's persistent form: one workgroup per CU walks tiles w, w + 256, ... and issues the next tile's first
+    loads from inside the epilogue.  111 x 111 pixels x batch 5 (6) = 276 tiles of 224 rows (289 of 256 rows x 192
+    channels), the last one ragged; in the XCD-aware order that tile is some workgroup's FIRST, so the row-guarded
+    epilogue is also the one that starts a next tile.  Forward, masked and plain dgrad against the 128 x 128 kernel:
+    every output element accumulates the same K-steps in the same order, so the results are equal bit for bit."""
+    from yolo_from_scratch_amd import _lib as L
+    hw = 111
+    g = torch.Generator().manual_seed(n * 100 + cin)
+    if op == "fwd":
+        x = co.nhwc(torch.randn(n, cin, hw, hw, generator=g).to(DEV), torch.bfloat16)
+        w = co.nhwc(((torch.rand(cout, cin, 3, 3, generator=g) * 2 - 1) / (cin * 9) ** 0.5).to(DEV))
+        b = (torch.rand(cout, generator=g) - 0.5).to(DEV)
+        w16 = co.weight_prep(w, want_wt16=False)[0]
+        run = lambda: co.conv_fwd(x, w16, b, 1)
+        want = "igemm8_kernel<224,256,epi0>"
+    else:
+        dz = co.nhwc(torch.randn(n, cout, hw, hw, generator=g).to(DEV), torch.bfloat16)
+        act = co.nhwc(torch.randn(n, cin, hw, hw, generator=g).to(DEV), torch.bfloat16) if op == "dgrad" else None
+        w = co.nhwc(((torch.rand(cout, cin, 3, 3, generator=g) * 2 - 1) / (cout * 9) ** 0.5).to(DEV))
+        wt16 = co.weight_prep(w)[1]
+        run = lambda: co.conv_dgrad(dz, wt16, (hw, hw), 1, x_act=act)
+        want = {87: "igemm8_kernel<224,256,epi%d>" % (1 if op == "dgrad" else 2), 192: "igemm8_kernel<256,192,epi1>"}[knob]
+    split = co.SPLIT_K
+    co.SPLIT_K = False
+    try:
+        L.set_knob("igemm_tile", 128)
+        ref = run()
+        L.set_knob("igemm_tile", knob)
+        got = run()
+        assert L.last_kernel() == want, L.last_kernel()
+        again = run()            # and the same bits on a second launch (nothing left behind in LDS or flags)
+    finally:
+        L.set_knob("igemm_tile", 0)
+        co.SPLIT_K = split
+    assert torch.equal(got, ref)
+    assert torch.equal(again, ref)
