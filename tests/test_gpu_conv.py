@@ -565,3 +565,41 @@ def test_persistent_8phase_kernel_on_more_tiles_than_cus_with_a_ragged_last_tile
         co.SPLIT_K = split
     assert torch.equal(got, ref)
     assert torch.equal(again, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,cin,cout,k,hw,stride", [("feat.2", 192, 256, 3, 112, 1), ("feat.7", 256, 512, 3, 56, 1), ("feat.17", 512, 512, 1, 28, 1),
+                                                      ("feat.18", 512, 1024, 3, 28, 1), ("feat.25", 1024, 1024, 3, 14, 2),
+                                                      ("feat.26", 1024, 1024, 3, 7, 1)])
+def test_full_size_layers_are_homogeneous_under_powers_of_two(name, cin, cout, k, hw, stride):
+    """A size-independent property at BASELINE config 2's full sizes (batch 64), where the oracle would take minutes per
+    layer: multiplying an operand by a power of two multiplies every bf16 product, every fp32 partial sum and every rounded
+    output by it exactly, so dgrad(4 dz) == 4 dgrad(dz), masked or not, wgrad(x, 4 dz) == 4 wgrad(x, dz) == wgrad(4 x, dz), and with a zero
+    bias forward(4 x) == 4 forward(x), pooled or not, BIT FOR BIT, whatever tile, split or persistent schedule the dispatch picks for the real shape (the kernels that run:
+    8-phase persistent, 192-channel tile, split-K + reduction, strided dgrad, wgrad8 with its slab reduction)."""
+    n = 64
+    g = torch.Generator().manual_seed(len(name) * 7 + hw)
+    ho, wo = co.out_hw(hw, hw, k, stride)
+    x = co.nhwc((torch.rand(n, cin, hw, hw, generator=g) - 0.3).to(DEV), torch.bfloat16)
+    dz = co.nhwc((torch.randn(n, cout, ho, wo, generator=g) * 0.05).to(DEV), torch.bfloat16)
+    w = co.nhwc(((torch.rand(cout, cin, k, k, generator=g) * 2 - 1) / (cin * k * k) ** 0.5).to(DEV))
+    wt16 = co.weight_prep(w)[1]
+    dz4, x4 = dz * 4, x * 4
+    for act in (x, None):
+        a = co.conv_dgrad(dz, wt16, (hw, hw), stride, x_act=act)
+        b = co.conv_dgrad(dz4, wt16, (hw, hw), stride, x_act=act)
+        assert torch.equal(a * 4, b), (name, "dgrad", act is not None)
+        assert float(a.float().abs().max()) > 0
+    dw, db = co.conv_wgrad(x, dz, k, stride)
+    dw4, db4 = co.conv_wgrad(x, dz4, k, stride)
+    dwx, _ = co.conv_wgrad(x4, dz, k, stride)
+    assert torch.equal(dw * 4, dw4) and torch.equal(db * 4, db4) and torch.equal(dw * 4, dwx), (name, "wgrad")
+    assert float(dw.abs().max()) > 0
+    # forward with a zero bias: leaky(4 a) == 4 leaky(a); the fused pool picks the same window positions
+    w16 = co.weight_prep(w, want_wt16=False)[0]
+    zero = torch.zeros(cout, device=DEV)
+    y, y4 = co.conv_fwd(x, w16, zero, stride), co.conv_fwd(x4, w16, zero, stride)
+    assert torch.equal(y * 4, y4), (name, "forward")
+    if ho % 2 == 0 and wo % 2 == 0:
+        (p1, i1), (p4, i4) = co.conv_fwd_pool(x, w16, zero, stride), co.conv_fwd_pool(x4, w16, zero, stride)
+        assert torch.equal(p1 * 4, p4) and torch.equal(i1, i4), (name, "forward + pool")
