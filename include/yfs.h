@@ -51,9 +51,12 @@ int yfs_last_error(char *buf, size_t n);
  *   YFS_KNOB_WGRAD_TILE    weight-gradient tile: 64 | 12864 | 128 (wgrad_kernel, its own tile choice) | 8 (wgrad8_kernel: 256-wide tiles)
  *   YFS_KNOB_WGRAD_SPLITS  split-K factor of the weight gradient (> 0 forces it)
  *   YFS_KNOB_NMS_FUSED     1: yfs_decode_nms_f32 decodes inside the NMS kernel (one launch)
- *   YFS_KNOB_STEM_KERNEL   1: stem forward + pool on the tiled kernel instead of the weight-stationary one (bit-identical) */
+ *   YFS_KNOB_STEM_KERNEL   1: stem forward + pool on the tiled kernel instead of the weight-stationary one (bit-identical)
+ *   YFS_KNOB_IGEMM_PERSIST 1: igemm8_kernel as one workgroup per TILE instead of one persistent workgroup per CU
+ *                          (bit-identical; the hardware then hands tiles to whichever CU is free, which is what a process
+ *                          wants whose CUs are shared with long-running kernels of another queue, e.g. RCCL's) */
 typedef enum { YFS_KNOB_IGEMM_TILE = 0, YFS_KNOB_WGRAD_TILE = 1, YFS_KNOB_WGRAD_SPLITS = 2, YFS_KNOB_NMS_FUSED = 3,
-               YFS_KNOB_STEM_KERNEL = 4, YFS_KNOB_COUNT = 5 } yfs_knob_id;
+               YFS_KNOB_STEM_KERNEL = 4, YFS_KNOB_IGEMM_PERSIST = 5, YFS_KNOB_COUNT = 6 } yfs_knob_id;
 int yfs_set_knob(int knob, int value);
 int yfs_get_knob(int knob);
 /* Dispatch query (no reference counterpart: the reference has one conv code path, torch's): the kernel variant the

@@ -529,11 +529,13 @@ def test_dgrad_carried_through_the_pool_in_front_is_bit_identical(n, cin, cout, 
 @pytest.mark.parametrize("op,n,cin,cout,knob", [("fwd", 5, 64, 256, 87), ("dgrad", 5, 256, 64, 87), ("dgrad_plain", 5, 256, 64, 87),
                                                 ("dgrad", 6, 192, 64, 192)])
 def test_persistent_8phase_kernel_on_more_tiles_than_cus_with_a_ragged_last_tile(op, n, cin, cout, knob):
-    """igemm8_kernel's persistent form: one workgroup per CU walks tiles w, w + 256, ... and issues the next tile's first
-    loads from inside the epilogue.  111 x 111 pixels x batch 5 (6) = 276 tiles of 224 rows (289 of 256 rows x 192
-    channels), the last one ragged; in the XCD-aware order that tile is some workgroup's FIRST, so the row-guarded
-    epilogue is also the one that starts a next tile.  Forward, masked and plain dgrad against the 128 x 128 kernel:
-    every output element accumulates the same K-steps in the same order, so the results are equal bit for bit."""
+    """igemm8_kernel on more tiles than the chip has CUs.  The forward form is persistent: one workgroup per CU walks tiles
+    w, w + 256, ... and issues the next tile's first loads from inside the epilogue.  111 x 111 pixels x batch 5 (6) = 276
+    tiles of 224 rows (289 of 256 rows x 192 channels), the last one ragged; in the XCD-aware order that tile is some
+    workgroup's FIRST, so the row-guarded epilogue is also the one that starts a next tile.  Forward, masked and plain
+    dgrad (one workgroup per tile, second round of the grid) against the 128 x 128 kernel: every output element
+    accumulates the same K-steps in the same order, so the results are equal bit for bit.  The forward case also runs
+    with YFS_KNOB_IGEMM_PERSIST = 1 (one workgroup per tile)."""
     from yolo_from_scratch_amd import _lib as L
     hw = 111
     g = torch.Generator().manual_seed(n * 100 + cin)
@@ -560,11 +562,15 @@ def test_persistent_8phase_kernel_on_more_tiles_than_cus_with_a_ragged_last_tile
         got = run()
         assert L.last_kernel() == want, L.last_kernel()
         again = run()            # and the same bits on a second launch (nothing left behind in LDS or flags)
+        L.set_knob("igemm_persist", 1)
+        per_tile = run()
     finally:
+        L.set_knob("igemm_persist", 0)
         L.set_knob("igemm_tile", 0)
         co.SPLIT_K = split
     assert torch.equal(got, ref)
     assert torch.equal(again, ref)
+    assert torch.equal(per_tile, ref)
 
 
 @pytest.mark.gpu

@@ -33,7 +33,7 @@ def lib():
     return _lib
 
 
-KNOBS = {"igemm_tile": 0, "wgrad_tile": 1, "wgrad_splits": 2, "nms_fused": 3, "stem_kernel": 4}     # include/yfs.h: yfs_knob_id
+KNOBS = {"igemm_tile": 0, "wgrad_tile": 1, "wgrad_splits": 2, "nms_fused": 3, "stem_kernel": 4, "igemm_persist": 5}     # include/yfs.h: yfs_knob_id
 
 
 def set_knob(name, value):

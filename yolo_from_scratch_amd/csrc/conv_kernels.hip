@@ -674,13 +674,20 @@ __device__ long long yfs_ig8_tl[8192 * 6];
 #endif
 // FW1 = channel fragments per wave in the SECOND weight half-tile: 2 -> 256-channel tile, 1 -> 192-channel tile (W1 holds
 // 64 rows, its MFMA blocks are half as long): feat.2's dgrad writes 192 channels.
-// Persistent forms: all but the pool-fused epilogue (it parks the tile in the LDS the next tile's loads would land in), the
-// 256 x 256 tile (128 accumulators + the epilogue's preloaded operands + the next tile's staging state do not fit in 256
-// registers: the compiler spills, and a scratch access next to the counted vmcnt waits would miscount them) and the
-// split-K form (its grids are at most one workgroup per CU by construction, and with the K-range state carried around a
-// tile loop the compiler keeps it in vector registers: feat.26 forward 71 -> 77 us).
+// Persistent form: the plain forward launches (bias + LeakyReLU) only.
+//  - not the dgrad forms: they share the chip with the weight-gradient stream and, in a data-parallel step, with RCCL's
+//    kernels, and a static assignment of tiles to workgroups cannot give way: with 16-64 workgroups of another queue
+//    holding CUs for milliseconds, feat.7's 1792 tiles took 643-667 us persistent against 454-543 us as one workgroup per
+//    tile, which the hardware hands to whichever CU is free (tools/probes/persist_under_contention.py); inside the
+//    two-stream training step persistent dgrads measured +-0.02 ms of 10.98.  The forward pass has the chip to itself;
+//  - not the pool-fused epilogue (it parks the tile in the LDS the next tile's loads would land in);
+//  - not the 256 x 256 tile (128 accumulators + the epilogue's preloaded operands + the next tile's staging state do not fit
+//    in 256 registers: the compiler spills, and a scratch access next to the counted vmcnt waits would miscount them);
+//  - not the split-K form (its grids are at most one workgroup per CU by construction, and with the K-range state carried
+//    around a tile loop the compiler keeps it in vector registers: feat.26 forward 71 -> 77 us).
+// YFS_KNOB_IGEMM_PERSIST = 1 turns it off for the forward launches too.
 template <int EPI, int FP1, int FW1>
-constexpr bool igemm8_persistent() { return EPI != EPI_POOL && EPI != EPI_PARTIAL && !(FP1 == 4 && FW1 == 2); }
+constexpr bool igemm8_persistent() { return EPI == EPI_BIAS_LEAKY && !(FP1 == 4 && FW1 == 2); }
 
 template <int EPI, int FP1, int FW1 = 2>
 __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
@@ -1151,7 +1158,7 @@ int launch_igemm8(IgemmArgs& g, hipStream_t s, const char* name) {
     YFS_REQUIRE(e == hipSuccess, YFS_ERR_LAUNCH, "%s: cannot reserve %d bytes of LDS", name, B8_LDS_IG);
     const int copies = EPI == EPI_PARTIAL ? g.ksplit : 1;
     int grid = g.mtiles * g.ntiles * copies;
-    if (igemm8_persistent<EPI, FP1, FW1>()) {   // one workgroup per CU walks the tiles (the kernel strides by gridDim.x)
+    if (igemm8_persistent<EPI, FP1, FW1>() && yfs_knob(YFS_KNOB_IGEMM_PERSIST) == 0) {   // one workgroup per CU walks the tiles (the kernel strides by gridDim.x)
         const int cus = cu_count();
         YFS_REQUIRE(cus > 0, YFS_ERR_LAUNCH, "%s: cannot read the device's CU count", name);
         if (grid > cus) grid = cus;

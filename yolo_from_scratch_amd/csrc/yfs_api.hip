@@ -50,7 +50,8 @@ YFS_API int yfs_last_error(char* buf, size_t n) {
 namespace {
 std::atomic<int> g_knob[YFS_KNOB_COUNT];
 std::once_flag g_knob_once;
-const char* const kKnobEnv[YFS_KNOB_COUNT] = {"YFS_IGEMM_TILE", "YFS_WGRAD_TILE", "YFS_WGRAD_SPLITS", "YFS_NMS_FUSED", "YFS_STEM_KERNEL"};
+const char* const kKnobEnv[YFS_KNOB_COUNT] = {"YFS_IGEMM_TILE", "YFS_WGRAD_TILE", "YFS_WGRAD_SPLITS", "YFS_NMS_FUSED", "YFS_STEM_KERNEL",
+                                                   "YFS_IGEMM_PERSIST"};
 void knob_init() {   // the environment gives the initial values, read exactly once: a later yfs_set_knob always wins
     std::call_once(g_knob_once, [] {
         for (int k = 0; k < YFS_KNOB_COUNT; ++k) {
