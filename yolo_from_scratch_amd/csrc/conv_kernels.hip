@@ -918,7 +918,8 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
     if (wm == 0) bar();   // catch up with waves 4-7: every wave is past its last fragment read after this
     IG8_T(2, vb);
     // the finished tile, and whether another follows (its prologue goes out from inside the epilogue)
-    const int cm0 = m0, cn0 = n0, csplit = split, cvb = vb;
+    const int cm0 = m0, cn0 = n0, csplit = split;
+    [[maybe_unused]] const int cvb = vb;   // (section clocks of the timing build)
     vb += (int)gridDim.x;
     const bool more = PERSIST && vb < total;
 
@@ -983,7 +984,7 @@ __global__ void __launch_bounds__(512, 2) igemm8_kernel(IgemmArgs g) {
             auto emit = [&](int m, float (&v)[8], const bf16x8& pre) {   // the lane's 8 channels of output row m
                 if (GUARD && m >= Mc) return;
                 const long long o = (long long)m * g.NOUT + c;
-                bf16x8 av;
+                bf16x8 av = {};
                 if (EPI == EPI_MASK) av = PRELOAD ? pre : *reinterpret_cast<const bf16x8*>(g.act + o);
                 epi_emit8<EPI>(g, o, v, svs[wh], bvs[wh], av);
             };
