@@ -316,6 +316,9 @@ def train_one_epoch(model, loader, device, opt, scaler, loss_fn, max_norm=1.0):
     # The caller's heap is thawed again before returning.
     gc.collect()
     gc.freeze()
+    # The loss scale is followed on the host (read from the scaler once per epoch; this loop is the only writer), so the
+    # scaler path pays ONE host read per step, opt.step's finite check — what torch.amp.GradScaler.step itself pays.
+    scale = float(scaler.get_scale()) if (flat and scaler is not None and scaler.is_enabled()) else 1.0
     try:
         for xb, yb in loader:
             xb = xb.to(device, non_blocking=True)
@@ -326,9 +329,10 @@ def train_one_epoch(model, loader, device, opt, scaler, loss_fn, max_norm=1.0):
             if scaler is not None and scaler.is_enabled():
                 scaler.scale(loss).backward()
                 if flat:
-                    scale = float(scaler.get_scale())
                     ok = opt.step(max_norm=max_norm, grad_scale=1.0 / scale)
-                    scaler.update(scale if ok else scale * scaler.get_backoff_factor())
+                    if not ok:
+                        scale *= scaler.get_backoff_factor()
+                    scaler.update(scale)
                 else:
                     scaler.unscale_(opt)
                     if max_norm is not None:
