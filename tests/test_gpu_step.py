@@ -107,26 +107,31 @@ def test_full_config2_step_is_bitwise_reproducible():
     """Race check for the two-stream backward (weight gradients on a side stream, model.py _BackboneFn.backward) and the
     split-K reductions: the full BASELINE configs[1] step (448x448, batch 64, dropout off) run twice from identical
     state must leave bitwise identical parameters, momentum and bf16 shadow.  A missing event between a side-stream
-    weight gradient and the optimiser, or an order-dependent reduction, shows up as a difference."""
+    weight gradient and the optimiser, or an order-dependent reduction, shows up as a difference.
+    The third run leaves fc.1's fused step running behind the next forward pass (FlatSGD.overlap_tail, what
+    train_one_epoch and bench.py do): same bits, i.e. the next fc.1 forward, the next step and join() wait for it."""
     assert ym._TWO_STREAMS
     tnp = synth.v1_targets(64, seed=1)
     x = torch.rand(64, 3, 448, 448, generator=torch.Generator().manual_seed(0)).to(DEV)
     tgt = torch.from_numpy(tnp).to(DEV)
     crit = y.YoloV1Loss(7, 2, 20)
     outs = []
-    for run in range(2):
+    for overlap in (False, False, True):
         torch.manual_seed(0)
         net = ym.YoloRegressorModel(head_out=1470, p_drop=0.0).to(DEV)
-        opt = yt.FlatSGD(net.parameters(), lr=1e-3, momentum=0.9, weight_decay=5e-4, max_norm=1.0)
-        for _ in range(2):
+        opt = yt.FlatSGD(net.parameters(), lr=1e-3, momentum=0.9, weight_decay=5e-4, max_norm=1.0, overlap_tail=overlap)
+        for _ in range(3):
             opt.zero_grad()
             crit(net(x), tgt).backward()
             opt.step()
-        torch.cuda.synchronize()
+        assert (opt._tail is not None) == overlap
+        opt.join()                      # current stream behind the last fused step; the clones below are ordered after it
         outs.append((opt.flat_p.clone(), opt.flat_m.clone(), opt.flat_p16.clone()))
+        torch.cuda.synchronize()
         del net, opt
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
 
 
 def test_enabled_grad_scaler_gives_the_same_step():

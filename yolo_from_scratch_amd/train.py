@@ -53,7 +53,7 @@ class FlatSGD(torch.optim.Optimizer):
     ``comm`` (optional) is a gradient-exchange object with ``reduce(flat_grads)`` (see dp.py).
     """
 
-    def __init__(self, params, lr=1e-3, momentum=0.9, weight_decay=5e-4, max_norm=None, comm=None):
+    def __init__(self, params, lr=1e-3, momentum=0.9, weight_decay=5e-4, max_norm=None, comm=None, overlap_tail=False):
         params = list(params)
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
         if not params or not all(p.is_cuda for p in params):
@@ -106,6 +106,17 @@ class FlatSGD(torch.optim.Optimizer):
             for p in params:
                 p._yfs_comm = comm
         self._first = True
+        # overlap_tail: the fused step of a deferred Linear weight (fc.1: 3.7 GB of HBM traffic, no matrix work) is
+        # enqueued on the weight-gradient stream and step() returns with it in flight, so it runs under the next
+        # forward pass's convolutions (matrix-bound, little HBM traffic).  Everything in this package that reads such a
+        # parameter waits for it first (bf16_shadow -> the Linear forward, step(), train_one_epoch's end); code that reads
+        # the parameter tensor itself right after step() must call join().  Off by default for that reason;
+        # train_one_epoch switches it on for its own loop.
+        self.overlap_tail = bool(overlap_tail)
+        self._tail = None
+        for p in params:
+            if p._yfs_defer:
+                p._yfs_tail_owner = self
         self._sumsq = torch.zeros(1, device=dev, dtype=torch.float32)
         ws_bytes = L.lib().yfs_sumsq_workspace_bytes(L.i64(total))
         self._ws = torch.empty(ws_bytes // 4 + 1, device=dev, dtype=torch.float32)
@@ -149,6 +160,11 @@ class FlatSGD(torch.optim.Optimizer):
     def _all_params(self):
         for group in self.param_groups:
             yield from group["params"]
+
+    def join(self):
+        """The current stream waits for a Linear step that ``overlap_tail`` left running on the side stream."""
+        if self._tail is not None:
+            torch.cuda.current_stream().wait_event(self._tail)
 
     @torch.no_grad()
     def grad_norm(self):
@@ -199,14 +215,29 @@ class FlatSGD(torch.optim.Optimizer):
                                              L.ptr(sumsq), L.c_float(max_norm or 0.0), L.c_float(g["lr"]),
                                              L.c_float(g["momentum"]), L.c_float(g["weight_decay"]), first,
                                              L.ptr(self.flat_p16[a:b]), L.stream()), "yfs_sgd_step_f32")
-        for p in deferred:
-            x16, dy16, gs = p._yfs_factors
-            o, sz = p._yfs_region
-            shape = tuple(p.shape)
-            fo.linear_wgrad_sgd(x16, dy16, self.flat_p[o:o + sz].view(shape), self.flat_m[o:o + sz].view(shape),
-                                self.flat_p16[o:o + sz].view(shape), sumsq, max_norm, g["lr"], g["momentum"], g["weight_decay"],
-                                self._first, gs)
-            p._yfs_factors = None
+        def linear_steps():
+            for p in deferred:
+                x16, dy16, gs = p._yfs_factors
+                o, sz = p._yfs_region
+                shape = tuple(p.shape)
+                fo.linear_wgrad_sgd(x16, dy16, self.flat_p[o:o + sz].view(shape), self.flat_m[o:o + sz].view(shape),
+                                    self.flat_p16[o:o + sz].view(shape), sumsq, max_norm, g["lr"], g["momentum"],
+                                    g["weight_decay"], self._first, gs)
+                p._yfs_factors = None
+
+        if self.overlap_tail:
+            from .model import _side_stream
+            side = _side_stream(self.flat_p.device)
+            side.wait_stream(torch.cuda.current_stream())      # the norm and the factors are produced on this stream
+            with torch.cuda.stream(side):
+                for p in deferred:
+                    for t in p._yfs_factors[:2]:
+                        t.record_stream(side)
+                linear_steps()
+                self._tail = torch.cuda.Event()
+                self._tail.record(side)
+        else:
+            linear_steps()
         self._first = False
         return True
 
@@ -219,6 +250,8 @@ class FlatSGD(torch.optim.Optimizer):
         gradient is not finite, which is what torch.amp.GradScaler.step does; True otherwise."""
         if max_norm == "default":
             max_norm = self.max_norm
+        self.join()              # last step's overlapped Linear update reads the norm buffer this step rewrites
+        self._tail = None
         self._finish_grads()
         if self.comm is not None:
             self.comm.reduce(self.flat_g)
@@ -253,6 +286,9 @@ def bf16_shadow(param):
     sh = getattr(param, "_yfs_bf16", None)
     if sh is None:
         return None
+    owner = getattr(param, "_yfs_tail_owner", None)
+    if owner is not None:
+        owner.join()
     if param._version != param._yfs_bf16_ver:      # written in place since the last step (e.g. load_state_dict)
         with torch.no_grad():
             sh.copy_(param.detach())
@@ -319,6 +355,11 @@ def train_one_epoch(model, loader, device, opt, scaler, loss_fn, max_norm=1.0):
     # The loss scale is followed on the host (read from the scaler once per epoch; this loop is the only writer), so the
     # scaler path pays ONE host read per step, opt.step's finite check — what torch.amp.GradScaler.step itself pays.
     scale = float(scaler.get_scale()) if (flat and scaler is not None and scaler.is_enabled()) else 1.0
+    # Inside this loop nothing reads fc.1's weight between a step and the next forward pass, so the fused step of that
+    # weight runs behind the next batch's convolutions (FlatSGD.overlap_tail); joined before returning.
+    overlap_before = opt.overlap_tail if flat else False
+    if flat:
+        opt.overlap_tail = True
     try:
         for xb, yb in loader:
             xb = xb.to(device, non_blocking=True)
@@ -351,5 +392,8 @@ def train_one_epoch(model, loader, device, opt, scaler, loss_fn, max_norm=1.0):
             n += xb.size(0)
     finally:
         gc.unfreeze()
+        if flat:
+            opt.overlap_tail = overlap_before
+            opt.join()
     train_one_epoch.last_count = n
     return running.item() / n
