@@ -3,7 +3,7 @@
 #   bash tools/evidence_single_stream.sh <tag>
 # bench.py's roofline.achieved divides the conv FLOPs of a step by HIP-event brackets taken with the weight-gradient
 # stream off.  This runs the same command with that stream off for the WHOLE process under rocprofv3 --kernel-trace
-# --stats, so the per-kernel average durations in the stats are those of kernels running alone; the conv rows (igemm*,
+# --stats, (and the overlapped optimiser tail), so the per-kernel average durations in the stats are those of kernels running alone; the conv rows (igemm*,
 # wgrad*, stem_pool, splitk_*) summed per step must agree with roofline.conv_ms_per_step of the same run.
 set -eo pipefail
 tag=${1:-x}
@@ -13,6 +13,7 @@ mkdir -p "$out"
 cd /tmp
 export TMPDIR=/tmp
 export YFS_WGRAD_STREAM=0
+export YFS_OVERLAP_TAIL=0     # nor the optimiser tail of the previous step behind the first convolutions
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d "$out/prof" -o bench --output-format csv -- \
     python3 "$root/bench.py" --steps 20 --warmup 5 --no-nms --no-cpu-baseline > "$out/bench.json" 2> "$out/bench.err"
 find "$out/prof" -name '*kernel_trace.csv' -delete
