@@ -114,6 +114,7 @@ class FlatSGD(torch.optim.Optimizer):
         # train_one_epoch switches it on for its own loop.
         self.overlap_tail = bool(overlap_tail)
         self._tail = None
+        self._tail_recorded = False
         for p in params:
             if p._yfs_defer:
                 p._yfs_tail_owner = self
@@ -233,6 +234,10 @@ class FlatSGD(torch.optim.Optimizer):
                 for p in deferred:
                     for t in p._yfs_factors[:2]:
                         t.record_stream(side)
+                if not self._tail_recorded:      # the arenas must outlive that stream's work if the optimiser is dropped
+                    for t in (self.flat_p, self.flat_m, self.flat_p16, self._sumsq):
+                        t.record_stream(side)
+                    self._tail_recorded = True
                 linear_steps()
                 self._tail = torch.cuda.Event()
                 self._tail.record(side)
