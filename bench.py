@@ -606,7 +606,11 @@ def main():
             "final_loss": round(final_loss, 5),
             "roofline": {"bound": "mfma", "kernel": "conv implicit-GEMM set (igemm_kernel / igemm8_kernel / stem_pool_kernel fwd+dgrad, wgrad_kernel / wgrad8_kernel)",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                         # memory-side bytes of the conv kernels per step (committed PMC passes, like mfma_busy_pmc below)
+                         "traffic": (lambda v, src: float(v["conv"]) if v and v.get("conv") else None)(
+                             *committed_pmc("pmc_traffic_conv_step.txt")),
+                         "traffic_source": committed_pmc("pmc_traffic_conv_step.txt")[1],
                          "algorithmic_tflop_per_step": round(conv_flops / 1e12, 4), "conv_ms_per_step": round(conv_ms, 3),
                          "mfma_busy_pmc": dict(zip(("kernels", "source"), committed_pmc("conv_pmc_summary.txt"))),
                          "measured_over": "%d extra steps with the weight-gradient stream off (non-overlapping "
